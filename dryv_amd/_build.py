@@ -1,0 +1,60 @@
+"""Builds the native libraries of the package in-tree (dryv_amd/lib/*.so).
+
+* libdryv_recon.so — the product: gfx950 HIP kernels + the extern "C" boundary
+  (include/dryv_recon.h). Cross-compiles without a GPU.
+* libdryv_synth.so — host-only synthetic batch generator (tests / bench inputs).
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+RECON_SO = os.path.join(LIB, "libdryv_recon.so")
+SYNTH_SO = os.path.join(LIB, "libdryv_synth.so")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_recon(force=False):
+    srcs = [os.path.join(CSRC, f) for f in ("recon_kernel.hip", "recon_api.hip")]
+    deps = srcs + [os.path.join(CSRC, "recon_kernel.h"),
+                   os.path.join(HERE, "..", "include", "dryv_recon.h")]
+    os.makedirs(LIB, exist_ok=True)
+    if force or _stale(RECON_SO, deps):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-o", RECON_SO] + srcs)
+    return RECON_SO
+
+
+def build_synth(force=False):
+    src = os.path.join(CSRC, "synth.c")
+    deps = [src, os.path.join(HERE, "..", "include", "dryv_recon.h")]
+    os.makedirs(LIB, exist_ok=True)
+    if force or _stale(SYNTH_SO, deps):
+        _run(["gcc", "-O2", "-fPIC", "-std=c11", "-Wall", "-shared", "-o", SYNTH_SO, src])
+    return SYNTH_SO
+
+
+def build_all(force=False):
+    return [build_recon(force), build_synth(force)]
+
+
+if __name__ == "__main__":
+    for p in build_all(force=True):
+        print("built", p)

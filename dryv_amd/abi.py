@@ -1,0 +1,125 @@
+"""ctypes view of include/dryv_recon.h — the C ABI of the reconstruction backend.
+
+The record layouts here must stay byte-identical to the header; tests/test_abi.py checks sizes,
+offsets and that every declared symbol is exported by libdryv_recon.so.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+DRYV_OK = 0
+DRYV_E_INVALID = -1
+DRYV_E_UNSUPPORTED = -2
+DRYV_E_DEVICE = -3
+DRYV_E_NOMEM = -4
+DRYV_E_STATE = -5
+DRYV_E_NODEVICE = -6
+
+COEFFS_PER_MB = 384
+
+
+class FrameParams(C.Structure):
+    """dryv_frame_params (496 bytes)."""
+    _fields_ = [
+        ("pic_width_in_mbs", C.c_uint16),
+        ("pic_height_in_mbs", C.c_uint16),
+        ("chroma_array_type", C.c_uint8),
+        ("bit_depth_y", C.c_uint8),
+        ("bit_depth_c", C.c_uint8),
+        ("chroma_qp_index_offset", C.c_int8),
+        ("second_chroma_qp_index_offset", C.c_int8),
+        ("constrained_intra_pred_flag", C.c_uint8),
+        ("transform_8x8_mode_flag", C.c_uint8),
+        ("reserved", C.c_uint8 * 5),
+        ("scaling_list4x4", (C.c_uint8 * 16) * 6),
+        ("scaling_list8x8", (C.c_uint8 * 64) * 6),
+    ]
+
+
+class MbDesc(C.Structure):
+    """dryv_mb_desc (16 bytes)."""
+    _fields_ = [
+        ("mb_kind", C.c_uint8),
+        ("i16_pred_mode", C.c_uint8),
+        ("intra_chroma_pred_mode", C.c_uint8),
+        ("qp", C.c_uint8),
+        ("prev_flags", C.c_uint16),
+        ("rem_modes", C.c_uint8 * 8),
+        ("nz_mask", C.c_uint16),
+    ]
+
+
+# numpy view of the same 16 bytes, for bulk handling
+MB_DESC_DTYPE = np.dtype([
+    ("mb_kind", "u1"), ("i16_pred_mode", "u1"), ("intra_chroma_pred_mode", "u1"), ("qp", "u1"),
+    ("prev_flags", "<u2"), ("rem_modes", "u1", (8,)), ("nz_mask", "<u2"),
+])
+assert MB_DESC_DTYPE.itemsize == 16 and C.sizeof(MbDesc) == 16 and C.sizeof(FrameParams) == 496
+
+# every function include/dryv_recon.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "dryv_recon_frame_bytes": (C.c_size_t, [C.POINTER(FrameParams)]),
+    "dryv_recon_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "dryv_recon_destroy": (None, [C.c_void_p]),
+    "dryv_recon_submit": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "dryv_recon_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dryv_recon_submit_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    "dryv_recon_sync": (C.c_int, [C.c_void_p]),
+    "dryv_recon_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "dryv_recon_stream": (C.c_void_p, [C.c_void_p]),
+    "dryv_recon_strerror": (C.c_char_p, [C.c_int]),
+    "dryv_recon_last_device_error": (C.c_char_p, [C.c_void_p]),
+    "dryv_recon_abi_version": (C.c_int, []),
+    "dryv_math_clamp": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "dryv_math_inverse_raster_scan": (C.c_int64, [C.c_int64] * 5),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libdryv_recon.so (building it first if the sources are newer). Raises if the HIP
+    extension is missing: there is no Python or CPU fallback for the path."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    so = path or _build.RECON_SO
+    if path is None and not os.path.exists(so):
+        so = _build.build_recon()
+    lib = C.CDLL(so)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def make_frame_params(width_mbs, height_mbs, cqo_cb=0, cqo_cr=None, transform_8x8=False,
+                      scaling4x4=None, scaling8x8=None, constrained_intra=False):
+    """Builds a dryv_frame_params. Scaling lists default to flat 16 (reference: header.rs:330)."""
+    fp = FrameParams()
+    fp.pic_width_in_mbs = width_mbs
+    fp.pic_height_in_mbs = height_mbs
+    fp.chroma_array_type = 1
+    fp.bit_depth_y = 8
+    fp.bit_depth_c = 8
+    fp.chroma_qp_index_offset = cqo_cb
+    fp.second_chroma_qp_index_offset = cqo_cb if cqo_cr is None else cqo_cr
+    fp.constrained_intra_pred_flag = int(constrained_intra)
+    fp.transform_8x8_mode_flag = int(transform_8x8)
+    for l in range(6):
+        for k in range(16):
+            fp.scaling_list4x4[l][k] = 16 if scaling4x4 is None else int(scaling4x4[l][k])
+        for k in range(64):
+            fp.scaling_list8x8[l][k] = 16 if scaling8x8 is None else int(scaling8x8[l][k])
+    return fp
+
+
+def strerror(status):
+    return load_library().dryv_recon_strerror(status).decode()

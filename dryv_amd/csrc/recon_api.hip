@@ -1,0 +1,345 @@
+// recon_api.hip — extern "C" boundary (include/dryv_recon.h) over the gfx950 reconstruction kernel.
+//
+// Host-side responsibilities only: validate the parameter block, derive the per-submit constant
+// tables (LevelScale, prediction gather tables), move buffers, launch, time, report status.
+// There is deliberately NO CPU implementation of the path in this library: without a HIP device
+// every entry point that would compute fails with DRYV_E_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "recon_kernel.h"
+
+using dryv::KParams;
+
+struct dryv_recon_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  unsigned* d_status = nullptr;
+  unsigned* h_status = nullptr;  // pinned
+  // host-buffer path: grow-only device staging
+  void* d_mbs = nullptr;
+  void* d_coeffs = nullptr;
+  void* d_yuv = nullptr;
+  size_t cap_mbs = 0, cap_coeffs = 0, cap_yuv = 0;
+  size_t pending_yuv_bytes = 0;
+  bool in_flight = false;        // a submit has not been waited for
+  bool in_flight_host = false;   // ... and it was a host-buffer submit
+  bool timed = false;
+  int nw_override = 0, grid_override = 0;
+  std::string last_error;
+};
+
+namespace {
+
+int fail(dryv_recon_ctx* ctx, hipError_t e, const char* what) {
+  if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return DRYV_E_DEVICE;
+}
+
+// frame/mod.rs:212-284 — (row, col) of 8x8 zig-zag list position k
+const uint8_t ZZ8[64][2] = {
+    {0, 0}, {0, 1}, {1, 0}, {2, 0}, {1, 1}, {0, 2}, {0, 3}, {1, 2}, {2, 1}, {3, 0}, {4, 0},
+    {3, 1}, {2, 2}, {1, 3}, {0, 4}, {0, 5}, {1, 4}, {2, 3}, {3, 2}, {4, 1}, {5, 0}, {6, 0},
+    {5, 1}, {4, 2}, {3, 3}, {2, 4}, {1, 5}, {0, 6}, {0, 7}, {1, 6}, {2, 5}, {3, 4}, {4, 3},
+    {5, 2}, {6, 1}, {7, 0}, {7, 1}, {6, 2}, {5, 3}, {4, 4}, {3, 5}, {2, 6}, {1, 7}, {2, 7},
+    {3, 6}, {4, 5}, {5, 4}, {6, 3}, {7, 2}, {7, 3}, {6, 4}, {5, 5}, {4, 6}, {3, 7}, {4, 7},
+    {5, 6}, {6, 5}, {7, 4}, {7, 5}, {6, 6}, {5, 7}, {6, 7}, {7, 6}, {7, 7}};
+// frame/mod.rs:185-209 — (row, col) of 4x4 zig-zag list position k
+const uint8_t ZZ4[16][2] = {{0, 0}, {0, 1}, {1, 0}, {2, 0}, {1, 1}, {0, 2}, {0, 3}, {1, 2},
+                            {2, 1}, {3, 0}, {3, 1}, {2, 2}, {1, 3}, {2, 3}, {3, 2}, {3, 3}};
+
+enum { SEL_E = 0, SEL_F = 1, SEL_G = 2 };
+uint8_t ent(int sel, int idx) { return (uint8_t)(idx | (sel << 5)); }
+
+// Prediction as a gather. The block's reference samples are laid out on one line
+//   E = [ left column bottom..top | corner | top row (+ top-right) ]
+// and F[i] = (E[i-1] + 2E[i] + E[i+1] + 2) >> 2, G[i] = (E[i] + E[i+1] + 1) >> 1 (ends replicated).
+// Every directional mode of 8.3.1.2 / 8.3.2.2 then reads exactly one of E/F/G per pixel
+// (pred4x4.rs:92-359, pred8x8.rs:294-692). n = 4: E[0..3]=L3..L0, E[4]=corner, E[5..12]=T0..T7;
+// n = 8: E[0..7]=L7..L0, E[8]=corner, E[9..24]=T0..T15.
+void build_pred_table(int n, uint8_t* t) {
+  const int C = n;          // index of the corner sample
+  const int T0 = n + 1;     // index of p[0,-1]
+  const int L0 = n - 1;     // index of p[-1,0]
+  for (int y = 0; y < n; y++)
+    for (int x = 0; x < n; x++) {
+      const int p = y * n + x;
+      t[0 * n * n + p] = ent(SEL_E, T0 + x);
+      t[1 * n * n + p] = ent(SEL_E, L0 - y);
+      t[2 * n * n + p] = 0;
+      t[3 * n * n + p] = ent(SEL_F, T0 + 1 + x + y);
+      t[4 * n * n + p] = ent(SEL_F, C + x - y);
+      {  // vertical-right
+        const int z = 2 * x - y, k = x - (y >> 1);
+        uint8_t e;
+        if (z >= 0) e = (z & 1) ? ent(SEL_F, C + k) : ent(SEL_G, C + k);
+        else if (z == -1) e = ent(SEL_F, C);
+        else e = ent(SEL_F, T0 - y + 2 * x);
+        t[5 * n * n + p] = e;
+      }
+      {  // horizontal-down
+        const int z = 2 * y - x, k = y - (x >> 1);
+        uint8_t e;
+        if (z >= 0) e = (z & 1) ? ent(SEL_F, C - k) : ent(SEL_G, L0 - k);
+        else if (z == -1) e = ent(SEL_F, C);
+        else e = ent(SEL_F, L0 + x - 2 * y);
+        t[6 * n * n + p] = e;
+      }
+      t[7 * n * n + p] = (y & 1) ? ent(SEL_F, T0 + 1 + x + (y >> 1)) : ent(SEL_G, T0 + x + (y >> 1));
+      {  // horizontal-up
+        const int z = x + 2 * y, k = y + (x >> 1);
+        const int zmax = 2 * n - 3;  // 5 for 4x4, 13 for 8x8
+        uint8_t e;
+        if (z < zmax) e = (z & 1) ? ent(SEL_F, n - 2 - k) : ent(SEL_G, n - 2 - k);
+        else if (z == zmax) e = ent(SEL_F, 0);
+        else e = ent(SEL_E, 0);
+        t[8 * n * n + p] = e;
+      }
+    }
+}
+
+int build_params(const dryv_frame_params* fp, uint32_t n_frames, KParams* P) {
+  if (!fp) return DRYV_E_INVALID;
+  if (fp->pic_width_in_mbs == 0 || fp->pic_height_in_mbs == 0 || fp->pic_width_in_mbs > 1024) return DRYV_E_INVALID;
+  if (fp->chroma_array_type != 1 || fp->bit_depth_y != 8 || fp->bit_depth_c != 8) return DRYV_E_UNSUPPORTED;
+  memset(P, 0, sizeof(*P));
+  P->W = fp->pic_width_in_mbs;
+  P->H = fp->pic_height_in_mbs;
+  P->n_frames = (int)n_frames;
+  P->cqo_cb = fp->chroma_qp_index_offset;
+  P->cqo_cr = fp->second_chroma_qp_index_offset;
+  // 8.5.9 (transform.rs:8-78). Only scaling list 0 of each size is ever read on this path
+  // (intra, luma call; chroma re-uses the tables: quirk Q3).
+  static const int V4[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+  static const int V8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                               {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+  int w4[4][4], w8[8][8];
+  for (int k = 0; k < 16; k++) w4[ZZ4[k][0]][ZZ4[k][1]] = fp->scaling_list4x4[0][k];
+  for (int k = 0; k < 64; k++) w8[ZZ8[k][0]][ZZ8[k][1]] = fp->scaling_list8x8[0][k];
+  for (int m = 0; m < 6; m++) {
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        const int cls = (i % 2 == 0 && j % 2 == 0) ? 0 : ((i % 2 == 1 && j % 2 == 1) ? 1 : 2);
+        P->ls4[m * 16 + i * 4 + j] = (uint16_t)(w4[i][j] * V4[m][cls]);
+      }
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < 8; j++) {
+        int cls;
+        if (i % 4 == 0 && j % 4 == 0) cls = 0;
+        else if (i % 2 == 1 && j % 2 == 1) cls = 1;
+        else if (i % 4 == 2 && j % 4 == 2) cls = 2;
+        else if ((i % 4 == 0 && j % 2 == 1) || (i % 2 == 1 && j % 4 == 0)) cls = 3;
+        else if ((i % 4 == 0 && j % 4 == 2) || (i % 4 == 2 && j % 4 == 0)) cls = 4;
+        else cls = 5;
+        P->ls8[m * 64 + i * 8 + j] = (uint16_t)(w8[i][j] * V8[m][cls]);
+      }
+  }
+  build_pred_table(4, P->t4);
+  build_pred_table(8, P->t8);
+  for (int k = 0; k < 64; k++) P->zz8i[ZZ8[k][0] * 8 + ZZ8[k][1]] = (uint8_t)k;
+  return DRYV_OK;
+}
+
+// waves per workgroup: as many macroblock rows in flight per frame as LDS allows, at least 2
+// (the ring needs two slots), at most 16.
+int pick_nw(const dryv_recon_ctx* ctx, int W, int H) {
+  int nw = ctx->nw_override > 0 ? ctx->nw_override : 8;
+  if (nw > 16) nw = 16;
+  if (nw > H && H >= 2) nw = H;
+  if (nw < 2) nw = 2;
+  while (nw > 2 && dryv::recon_lds_bytes(W, nw) > 160 * 1024) nw--;
+  return nw;
+}
+
+int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
+  if (*cap >= need) return DRYV_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t e = hipMalloc(p, need);
+  if (e != hipSuccess) {
+    ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return DRYV_E_NOMEM;
+  }
+  *cap = need;
+  return DRYV_OK;
+}
+
+int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv) {
+  hipError_t e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
+  const int nw = pick_nw(ctx, P.W, P.H);
+  int grid = ctx->grid_override > 0 ? ctx->grid_override : P.n_frames;
+  if (grid > P.n_frames) grid = P.n_frames;
+  e = hipEventRecord(ctx->ev_start, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, nw, grid, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "recon_kernel launch");
+  e = hipEventRecord(ctx->ev_stop, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemcpyAsync(status)");
+  ctx->timed = true;
+  return DRYV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dryv_recon_frame_bytes(const dryv_frame_params* fp) {
+  if (!fp) return 0;
+  return (size_t)384 * fp->pic_width_in_mbs * fp->pic_height_in_mbs;
+}
+
+int dryv_recon_abi_version(void) { return DRYV_RECON_ABI_VERSION; }
+
+int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
+  if (!out) return DRYV_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return DRYV_E_NODEVICE;
+  if (device_ordinal < 0 || device_ordinal >= n) return DRYV_E_INVALID;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return DRYV_E_NODEVICE;
+  dryv_recon_ctx* ctx = new (std::nothrow) dryv_recon_ctx();
+  if (!ctx) return DRYV_E_NOMEM;
+  ctx->device = device_ordinal;
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
+      (e = hipMalloc((void**)&ctx->d_status, 16)) != hipSuccess ||
+      (e = hipHostMalloc((void**)&ctx->h_status, 16, hipHostMallocDefault)) != hipSuccess) {
+    dryv_recon_destroy(ctx);
+    return DRYV_E_DEVICE;
+  }
+  *ctx->h_status = 0;
+  if (const char* s = getenv("DRYV_RECON_NW")) ctx->nw_override = atoi(s);
+  if (const char* s = getenv("DRYV_RECON_GRID")) ctx->grid_override = atoi(s);
+  *out = ctx;
+  return DRYV_OK;
+}
+
+void dryv_recon_destroy(dryv_recon_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_mbs) (void)hipFree(ctx->d_mbs);
+  if (ctx->d_coeffs) (void)hipFree(ctx->d_coeffs);
+  if (ctx->d_yuv) (void)hipFree(ctx->d_yuv);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int dryv_recon_submit(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const dryv_mb_desc* mbs,
+                      const int16_t* coeffs) {
+  if (!ctx || !mbs || !coeffs || n_frames == 0) return DRYV_E_INVALID;
+  if (ctx->in_flight) return DRYV_E_STATE;
+  KParams P;
+  int st = build_params(fp, n_frames, &P);
+  if (st != DRYV_OK) return st;
+  (void)hipSetDevice(ctx->device);
+  const size_t n_mbs = (size_t)n_frames * P.W * P.H;
+  const size_t b_mbs = n_mbs * sizeof(dryv_mb_desc), b_co = n_mbs * DRYV_COEFFS_PER_MB * sizeof(int16_t);
+  const size_t b_yuv = n_mbs * 384;
+  if ((st = ensure(ctx, &ctx->d_mbs, &ctx->cap_mbs, b_mbs)) != DRYV_OK) return st;
+  if ((st = ensure(ctx, &ctx->d_coeffs, &ctx->cap_coeffs, b_co)) != DRYV_OK) return st;
+  if ((st = ensure(ctx, &ctx->d_yuv, &ctx->cap_yuv, b_yuv)) != DRYV_OK) return st;
+  hipError_t e;
+  if ((e = hipMemcpyAsync(ctx->d_mbs, mbs, b_mbs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+    return fail(ctx, e, "H2D macroblock records");
+  if ((e = hipMemcpyAsync(ctx->d_coeffs, coeffs, b_co, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+    return fail(ctx, e, "H2D coefficients");
+  if ((st = launch(ctx, P, ctx->d_mbs, ctx->d_coeffs, ctx->d_yuv)) != DRYV_OK) return st;
+  ctx->pending_yuv_bytes = b_yuv;
+  ctx->in_flight = true;
+  ctx->in_flight_host = true;
+  return DRYV_OK;
+}
+
+int dryv_recon_wait(dryv_recon_ctx* ctx, uint8_t* yuv_out, size_t yuv_out_bytes) {
+  if (!ctx || !yuv_out) return DRYV_E_INVALID;
+  if (!ctx->in_flight || !ctx->in_flight_host) return DRYV_E_STATE;
+  if (yuv_out_bytes < ctx->pending_yuv_bytes) return DRYV_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipMemcpyAsync(yuv_out, ctx->d_yuv, ctx->pending_yuv_bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "D2H planes");
+  e = hipStreamSynchronize(ctx->stream);
+  ctx->in_flight = false;
+  ctx->in_flight_host = false;
+  if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
+  return *ctx->h_status ? DRYV_E_UNSUPPORTED : DRYV_OK;
+}
+
+int dryv_recon_submit_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const void* d_mbs,
+                             const void* d_coeffs, void* d_yuv_out) {
+  if (!ctx || !d_mbs || !d_coeffs || !d_yuv_out || n_frames == 0) return DRYV_E_INVALID;
+  if (ctx->in_flight && ctx->in_flight_host) return DRYV_E_STATE;
+  KParams P;
+  int st = build_params(fp, n_frames, &P);
+  if (st != DRYV_OK) return st;
+  (void)hipSetDevice(ctx->device);
+  if ((st = launch(ctx, P, d_mbs, d_coeffs, d_yuv_out)) != DRYV_OK) return st;
+  ctx->in_flight = true;
+  ctx->in_flight_host = false;
+  return DRYV_OK;
+}
+
+int dryv_recon_sync(dryv_recon_ctx* ctx) {
+  if (!ctx) return DRYV_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (!ctx->in_flight_host) ctx->in_flight = false;
+  if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
+  return *ctx->h_status ? DRYV_E_UNSUPPORTED : DRYV_OK;
+}
+
+int dryv_recon_last_kernel_ms(dryv_recon_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return DRYV_E_INVALID;
+  if (!ctx->timed) return DRYV_E_STATE;
+  hipError_t e = hipEventSynchronize(ctx->ev_stop);
+  if (e != hipSuccess) return fail(ctx, e, "hipEventSynchronize");
+  e = hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop);
+  if (e != hipSuccess) return fail(ctx, e, "hipEventElapsedTime");
+  return DRYV_OK;
+}
+
+void* dryv_recon_stream(dryv_recon_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+const char* dryv_recon_strerror(int status) {
+  switch (status) {
+    case DRYV_OK: return "ok";
+    case DRYV_E_INVALID: return "invalid argument";
+    case DRYV_E_UNSUPPORTED: return "outside the supported domain (intra 4:2:0 8-bit, mb_kind 0..2, qp 0..51)";
+    case DRYV_E_DEVICE: return "HIP runtime error";
+    case DRYV_E_NOMEM: return "out of memory";
+    case DRYV_E_STATE: return "call out of order";
+    case DRYV_E_NODEVICE: return "no HIP device (this library has no CPU path)";
+    default: return "unknown status";
+  }
+}
+
+const char* dryv_recon_last_device_error(dryv_recon_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+/* math.rs:109-117 */
+int64_t dryv_math_clamp(int64_t value, int64_t min, int64_t max) {
+  if (value < min) return min;
+  if (value > max) return max;
+  return value;
+}
+
+/* math.rs:119-125 */
+int64_t dryv_math_inverse_raster_scan(int64_t a, int64_t b, int64_t c, int64_t d, int64_t e) {
+  if (e == 0) return (a % (d / b)) * b;
+  return (a / (d / b)) * c;
+}
+
+}  // extern "C"

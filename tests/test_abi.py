@@ -1,0 +1,104 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/dryv_recon.h declares,
+and the ctypes/numpy record layouts match the header byte for byte. No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+from dryv_amd import _build, abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dryv_recon.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dryv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    _build.build_recon()
+    lib = C.CDLL(_build.RECON_SO)
+    names = declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libdryv_recon.so does not export %s" % n
+    # and the ctypes table covers exactly the header
+    assert sorted(abi.SYMBOLS) == names
+
+
+def test_record_layout_matches_header():
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "dryv_recon.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(dryv_frame_params), offsetof(dryv_frame_params, scaling_list4x4),
+         offsetof(dryv_frame_params, scaling_list8x8), offsetof(dryv_frame_params, chroma_qp_index_offset),
+         offsetof(dryv_frame_params, second_chroma_qp_index_offset), offsetof(dryv_frame_params, transform_8x8_mode_flag));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(dryv_mb_desc), offsetof(dryv_mb_desc, qp), offsetof(dryv_mb_desc, prev_flags),
+         offsetof(dryv_mb_desc, rem_modes), offsetof(dryv_mb_desc, nz_mask));
+  return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "l.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(td, "l")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe], text=True).split("\n")
+    fpv = [int(x) for x in out[0].split()]
+    mbv = [int(x) for x in out[1].split()]
+    F = abi.FrameParams
+    assert fpv == [C.sizeof(F), F.scaling_list4x4.offset, F.scaling_list8x8.offset, F.chroma_qp_index_offset.offset,
+                   F.second_chroma_qp_index_offset.offset, F.transform_8x8_mode_flag.offset]
+    assert fpv[0] == 496
+    M = abi.MbDesc
+    assert mbv == [C.sizeof(M), M.qp.offset, M.prev_flags.offset, M.rem_modes.offset, M.nz_mask.offset]
+    d = abi.MB_DESC_DTYPE
+    assert [d.itemsize, d.fields["qp"][1], d.fields["prev_flags"][1], d.fields["rem_modes"][1],
+            d.fields["nz_mask"][1]] == mbv
+
+
+def test_host_only_entry_points():
+    lib = abi.load_library()
+    assert lib.dryv_recon_abi_version() == 1
+    fp = abi.make_frame_params(120, 68)
+    assert lib.dryv_recon_frame_bytes(C.byref(fp)) == 3133440          # bytes per 1080p frame
+    assert lib.dryv_recon_frame_bytes(C.byref(abi.make_frame_params(240, 135))) == 12441600
+    assert lib.dryv_recon_frame_bytes(None) == 0
+    assert b"CPU" in lib.dryv_recon_strerror(abi.DRYV_E_NODEVICE)
+    # math.rs:109-125
+    assert lib.dryv_math_clamp(300, 0, 255) == 255 and lib.dryv_math_clamp(-1, 0, 255) == 0
+    assert lib.dryv_math_inverse_raster_scan(125, 16, 16, 1920, 0) == 80
+    assert lib.dryv_math_inverse_raster_scan(125, 16, 16, 1920, 1) == 16
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU the library must fail loudly, not compute on the CPU."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from dryv_amd import abi; "
+            "lib = abi.load_library(); h = C.c_void_p(); st = lib.dryv_recon_create(C.byref(h), 0); "
+            "print(st)" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip()
+    assert int(out.split()[-1]) == abi.DRYV_E_NODEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under dryv_amd/ (sources or the built .so) may import, link or mention oracle/."""
+    pkg = os.path.join(ROOT, "dryv_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".c")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "libdryv_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, fn
+                assert "dryv_oracle_" not in txt, fn
+    syms = subprocess.check_output(["nm", "-D", _build.RECON_SO], text=True)
+    assert "dryv_oracle" not in syms
+    needed = subprocess.check_output(["readelf", "-d", _build.RECON_SO], text=True)
+    assert "oracle" not in needed
