@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py — macroblocks/s of the MI355X reconstruction path on BASELINE.json's workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: every rank reconstructs its
+300-frame shard of the 1080p all-intra workload (BASELINE.json configs[1]; N GPUs = configs[3]'s
+300 frames per GPU, weak scaling) with inputs already resident in HBM. Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import dryv_amd
+from dryv_amd import shard, synth
+
+ALG_BYTES_PER_MB = 1168          # 768 B coefficients + 16 B record read, 384 B pixels written
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(fp, mbs, coeffs, n_frames, gpu_out, frame_bytes, sample_frames):
+    """Times the oracle (the bit-exact port of the reference's Rust path) on one host core over the
+    first `sample_frames` frames of the same workload, and uses the same run to verify the GPU output."""
+    import oracle
+    per = fp.pic_width_in_mbs * fp.pic_height_in_mbs
+    k = min(sample_frames, n_frames)
+    t0 = time.perf_counter()
+    st, want = oracle.reconstruct(fp, k, mbs[:k * per], coeffs[:k * per])
+    dt = time.perf_counter() - t0
+    got = gpu_out[:k * frame_bytes].cpu().numpy()
+    verified = bool(st == 0 and np.array_equal(got, want))
+    return {"value": k * per / dt, "unit": "macroblocks/s", "cores": 1, "kind": "port",
+            "sample": "first %d frames of the workload (%d macroblocks), oracle/dryv_oracle.c -O2, %.1f s"
+                      % (k, k * per, dt),
+            "gpu_output_verified_bit_exact": verified}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2_1080p_intra_4x4", choices=sorted(synth.WORKLOADS))
+    ap.add_argument("--frames-per-gpu", type=int, default=None)
+    ap.add_argument("--cpu-sample-frames", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)   # backend "nccl" is RCCL on ROCm
+
+    # ---- control plane: rank 0 decides, everyone receives (RCCL broadcast) ----------------------
+    cid, w, h, frames, t8, kw = synth.WORKLOADS[args.workload]
+    per_gpu = args.frames_per_gpu or frames
+    fp = dryv_amd.make_frame_params(w, h, transform_8x8=t8)
+    table = shard.partition_frames(per_gpu * world, world)
+    fp, table = shard.broadcast_control(fp, table, device, rank, world)
+    first, n_frames = table[rank]
+    per = fp.pic_width_in_mbs * fp.pic_height_in_mbs
+    n_mbs = n_frames * per
+    frame_bytes = per * 384
+
+    # ---- synthetic shard, generated on the host and made resident in HBM ------------------------
+    mbs, coeffs = synth.generate(fp, synth.config(**kw), cid, first, n_frames)
+    d_mbs = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).to(device)
+    d_coeffs = torch.from_numpy(coeffs).to(device)
+    d_out = torch.zeros(n_mbs * 384, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+
+    ctx = dryv_amd.ReconContext(local_rank)
+
+    def step():
+        ctx.submit_device(fp, n_frames, d_mbs.data_ptr(), d_coeffs.data_ptr(), d_out.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+        ctx.sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ctx.sync()                       # one launch in flight at a time: steps are serial passes
+        kernel_ms.append(ctx.last_kernel_ms())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    reports = shard.gather_reports(n_frames, n_mbs, shard.plane_checksum(d_out), device, world)
+    total_mbs = sum(r[1] for r in reports)
+
+    if rank == 0:
+        avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+        achieved = n_mbs * ALG_BYTES_PER_MB / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "macroblocks/s (1080p all-intra)" if args.workload.startswith("C2") else
+                      "macroblocks/s (4K all-intra)",
+            "value": total_mbs * args.steps / elapsed,
+            "unit": "macroblocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d macroblocks x %d frames per GPU, resident in HBM; "
+                                   "frames sharded contiguously, one rank per GPU, no data-path collective"
+                                   % (args.workload, w, h, n_frames),
+                       "frames_per_gpu": n_frames, "macroblocks_per_step": total_mbs},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "recon_kernel", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": n_mbs * ALG_BYTES_PER_MB},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(fp, mbs, coeffs, n_frames, d_out, frame_bytes,
+                                                args.cpu_sample_frames)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,31 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; libdryv_recon.so links
+    the same SONAME from /opt/rocm. A process must only ever hold ONE HIP runtime, and torch cannot
+    initialise on a foreign one, so when torch is installed its copy is loaded first (without
+    importing torch) and libdryv_recon.so binds to it. Without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library(path=None):
     """Loads libdryv_recon.so (building it first if the sources are newer). Raises if the HIP
     extension is missing: there is no Python or CPU fallback for the path."""
@@ -90,6 +115,7 @@ def load_library(path=None):
     so = path or _build.RECON_SO
     if path is None and not os.path.exists(so):
         so = _build.build_recon()
+    _preload_torch_hip_runtime()
     lib = C.CDLL(so)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
