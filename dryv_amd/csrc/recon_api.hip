@@ -30,7 +30,11 @@ struct dryv_recon_ctx {
   bool in_flight = false;        // a submit has not been waited for
   bool in_flight_host = false;   // ... and it was a host-buffer submit
   bool timed = false;
-  int nw_override = 0, grid_override = 0;
+  // kernel workspace (task counter, per-row progress, bottom-row modes): grow-only
+  void* d_work = nullptr;
+  size_t cap_work = 0;
+  int num_cus = 256;
+  int grid_override = 0;
   std::string last_error;
 };
 
@@ -145,17 +149,6 @@ int build_params(const dryv_frame_params* fp, uint32_t n_frames, KParams* P) {
   return DRYV_OK;
 }
 
-// waves per workgroup: as many macroblock rows in flight per frame as LDS allows, at least 2
-// (the ring needs two slots), at most 16.
-int pick_nw(const dryv_recon_ctx* ctx, int W, int H) {
-  int nw = ctx->nw_override > 0 ? ctx->nw_override : 8;
-  if (nw > 16) nw = 16;
-  if (nw > H && H >= 2) nw = H;
-  if (nw < 2) nw = 2;
-  while (nw > 2 && dryv::recon_lds_bytes(W, nw) > 160 * 1024) nw--;
-  return nw;
-}
-
 int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
   if (*cap >= need) return DRYV_OK;
   if (*p) (void)hipFree(*p);
@@ -171,14 +164,21 @@ int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
 }
 
 int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv) {
+  int st = ensure(ctx, &ctx->d_work, &ctx->cap_work, dryv::recon_workspace_bytes(P.W, P.H, P.n_frames));
+  if (st != DRYV_OK) return st;
   hipError_t e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
-  const int nw = pick_nw(ctx, P.W, P.H);
-  int grid = ctx->grid_override > 0 ? ctx->grid_override : P.n_frames;
-  if (grid > P.n_frames) grid = P.n_frames;
+  e = dryv::recon_reset_workspace(P, ctx->d_work, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+  // Persistent grid: 4-wave workgroups, enough to hold 32 waves on every CU; each wave keeps claiming
+  // macroblock rows until none are left, so a smaller grid is merely slower and never incorrect.
+  const long long total_rows = (long long)P.n_frames * P.H;
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * 8;
+  if (grid > (total_rows + 3) / 4) grid = (total_rows + 3) / 4;
+  if (grid < 1) grid = 1;
   e = hipEventRecord(ctx->ev_start, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, nw, grid, ctx->stream);
+  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "recon_kernel launch");
   e = hipEventRecord(ctx->ev_stop, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
@@ -218,7 +218,11 @@ int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
     return DRYV_E_DEVICE;
   }
   *ctx->h_status = 0;
-  if (const char* s = getenv("DRYV_RECON_NW")) ctx->nw_override = atoi(s);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+      ctx->num_cus = prop.multiProcessorCount;
+  }
   if (const char* s = getenv("DRYV_RECON_GRID")) ctx->grid_override = atoi(s);
   *out = ctx;
   return DRYV_OK;
@@ -231,6 +235,7 @@ void dryv_recon_destroy(dryv_recon_ctx* ctx) {
   if (ctx->d_mbs) (void)hipFree(ctx->d_mbs);
   if (ctx->d_coeffs) (void)hipFree(ctx->d_coeffs);
   if (ctx->d_yuv) (void)hipFree(ctx->d_yuv);
+  if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -282,7 +287,9 @@ int dryv_recon_wait(dryv_recon_ctx* ctx, uint8_t* yuv_out, size_t yuv_out_bytes)
 int dryv_recon_submit_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const void* d_mbs,
                              const void* d_coeffs, void* d_yuv_out) {
   if (!ctx || !d_mbs || !d_coeffs || !d_yuv_out || n_frames == 0) return DRYV_E_INVALID;
-  if (ctx->in_flight && ctx->in_flight_host) return DRYV_E_STATE;
+  // 16-byte DMA of the coefficients, dword stores of the planes
+  if (((uintptr_t)d_mbs | (uintptr_t)d_coeffs | (uintptr_t)d_yuv_out) & 15u) return DRYV_E_INVALID;
+  if (ctx->in_flight) return DRYV_E_STATE;  // one batch at a time: the workspace belongs to the batch in flight
   KParams P;
   int st = build_params(fp, n_frames, &P);
   if (st != DRYV_OK) return st;

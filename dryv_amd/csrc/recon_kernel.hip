@@ -1,19 +1,27 @@
 // recon_kernel.hip — gfx950 (CDNA4 / MI355X) macroblock reconstruction for dryv's AVC intra path.
 //
 // Work decomposition
-//   * one workgroup per frame (frames are independent: SURVEY.md §8e), one 64-lane wavefront per
-//     macroblock ROW, rows of a frame advancing as a 2:1 diagonal: row r may process macroblock x once
-//     row r-1 has finished macroblock x+1 (top-right neighbour C; reference slice/macroblock.rs:455-456,
-//     slice/mod.rs:593-598). Progress is published through LDS counters (workgroup-scope
-//     release/acquire); the bottom pixel line and bottom-row prediction modes of each row live in an
-//     LDS ring slot for the row below. No neighbour sample is ever re-read from HBM.
+//   * The unit of work is one macroblock ROW of one frame, processed left to right by one 64-lane
+//     wavefront. Rows are claimed from a global queue in the order (row 0 of every frame, row 1 of every
+//     frame, ...): the row a task depends on was always claimed earlier, so its owner is running or done
+//     and a waiting wave can never deadlock, whatever the residency. Any wave on any CU can take any row:
+//     300 independent frames spread evenly over 256 CUs x 32 waves.
+//   * Rows of a frame advance as a 2:1 diagonal: row r may process macroblock x once row r-1 has
+//     published macroblock x+1 (top-right neighbour C; reference slice/macroblock.rs:455-456,
+//     slice/mod.rs:593-598). Hand-off between rows goes through L2 (MI355X_MICROARCH.md, "valid forms"):
+//     the producer stores each row's BOTTOM pixel line and bottom-row prediction modes write-through
+//     (sc1, relaxed agent-scope stores), waits for vmcnt(0), then stores its progress counter (sc1);
+//     the consumer polls that counter with sc1 loads and then reads the 25+9+9 neighbour samples and the
+//     modes with sc1 loads only (they bypass the CU's L1, so no acquire/invalidate is needed). All other
+//     pixel rows are plain write-back stores that L2 merges into full lines.
 //   * HBM traffic per macroblock: 768 B of coefficients in (one global->LDS DMA of 48 x 16 B, issued a
-//     macroblock ahead), a 16 B record, 384 B of pixels out (one dword per lane).
+//     macroblock ahead), a 16 B record, 384 B of pixels out (one dword per lane) + 4 B of modes, and a
+//     68 B neighbour window re-read through L2.
 //
 // Inside a macroblock (registers / DPP unless noted)
 //   * residual: 4 lanes per 4x4 block; lane = one row of coefficients (inverse zig-zag is a 4-way LDS
 //     gather), dequantise, row butterfly in-lane, DPP quad transpose, column butterfly in-lane.
-//   * Intra16x16 and chroma: predicted straight from the LDS line ring / left-edge bytes, clip-added,
+//   * Intra16x16 and chroma: predicted straight from the neighbour window / left-edge bytes, clip-added,
 //     packed 4 pixels per dword, byte-transposed across the quad (v_perm_b32) and stored.
 //   * Intra4x4: prediction modes by a 7-sweep DPP relaxation over the 4x4 block grid; pixels by a
 //     statically unrolled 10-step 2:1 block wavefront, 16 lanes per block: one LDS byte gather of the 13
@@ -72,7 +80,9 @@ struct WaveScratch {
   };
   uint8_t leftY[16];  // left neighbour's column x = 15 (contiguous copy)
   uint8_t leftC[2][8];
-  uint8_t pad[16];
+  // neighbour window of the row above, fetched per macroblock: Y x = -4..27, Cb x = -4..11, Cr x = -4..11,
+  // then the four bottom-row modes of macroblock B
+  uint8_t up[80];
 };
 static_assert(sizeof(WaveScratch) % 16 == 0, "scratch must keep 16-byte alignment");
 
@@ -229,28 +239,35 @@ __device__ __forceinline__ void i4_step(WaveScratch* ws, const I4Lane& L, const 
   ws->tileY[TY(4 * bx0, 4 * by0) + L.wrOff] = (uint8_t)clip255(pred + res);
 }
 
-__global__ void __launch_bounds__(1024)
+// relaxed agent-scope accesses: global_load/store ... sc1 (served by / written through L2, bypassing L1)
+__device__ __forceinline__ unsigned ld_sc1(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define UPY(k) (4 + (k))        // byte index in WaveScratch::up of luma sample x = k of the row above
+#define UPC(pl, k) (36 + 16 * (pl) + (k))
+#define UPM 64
+
+__global__ void __launch_bounds__(256, 8)
 recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_t* __restrict__ coeffs,
-             uint8_t* __restrict__ yuv, unsigned* __restrict__ status) {
+             uint8_t* __restrict__ yuv, unsigned* __restrict__ status, unsigned* __restrict__ rowProg,
+             unsigned* __restrict__ rowModes, unsigned* __restrict__ taskCounter) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
+  int lane = lane0;
   const int wave = rfl(threadIdx.x >> 6);
-  const int NW = blockDim.x >> 6;
   const int W = P.W, H = P.H;
 
   // ---- LDS carve ------------------------------------------------------------------------------
-  uint16_t* ls4 = (uint16_t*)(lds + 0);      // [6][16]
-  uint16_t* ls8 = (uint16_t*)(lds + 192);    // [6][64]
-  uint16_t* t4x = (uint16_t*)(lds + 960);    // [10][16]: (4*idx) | (8*sel) << 8; row 9 = zero prediction
-  uint8_t* t8 = lds + 1280;                  // [9][64]
-  uint8_t* zz8i = lds + 1856;                // [64] raster -> list index
-  unsigned* prog = (unsigned*)(lds + 1920);  // [16]
-  const int lineY_stride = W * 16 + 48;      // 16 bytes of slack in front, 32 behind
-  const int lineC_stride = W * 8 + 32;       // 16 in front, 16 behind
-  uint8_t* lineY = lds + 1984;
-  uint8_t* lineC = lineY + NW * lineY_stride;      // [NW][2][lineC_stride]
-  uint8_t* lineM = lineC + NW * 2 * lineC_stride;  // [NW][W*4] bottom-row modes
-  WaveScratch* ws = (WaveScratch*)(lineM + ((NW * W * 4 + 15) & ~15)) + wave;
+  uint16_t* ls4 = (uint16_t*)(lds + 0);    // [6][16]
+  uint16_t* ls8 = (uint16_t*)(lds + 192);  // [6][64]
+  uint16_t* t4x = (uint16_t*)(lds + 960);  // [10][16]: (4*idx) | (8*sel) << 8; row 9 = zero prediction
+  uint8_t* t8 = lds + 1280;                // [9][64]
+  uint8_t* zz8i = lds + 1856;              // [64] raster -> list index
+  WaveScratch* ws = (WaveScratch*)(lds + 1920) + wave;
 
   for (int i = threadIdx.x; i < 96; i += blockDim.x) ls4[i] = P.ls4[i];
   for (int i = threadIdx.x; i < 384; i += blockDim.x) ls8[i] = P.ls8[i];
@@ -263,77 +280,54 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   }
   for (int i = threadIdx.x; i < 576; i += blockDim.x) t8[i] = P.t8[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) zz8i[i] = P.zz8i[i];
-  if (threadIdx.x < 16) prog[threadIdx.x] = 0;
-  __syncthreads();
-
-  // ---- per-lane constants ---------------------------------------------------------------------
-  // "strip" organisation: 4 lanes per 4x4 block, sb = blkIdx (z-order), sq = row (then column) in the block
-  const int sq = lane & 3, sb = lane >> 2;
-  const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
-  const int sbx = ((sb >> 1) & 2) | (sb & 1), sby = ((sb >> 2) & 2) | ((sb >> 1) & 1);
-  const unsigned zz = sq == 0 ? 0x6510u : sq == 1 ? 0xC742u : sq == 2 ? 0xDB83u : 0xFEA9u;
-  const unsigned selA = odd ? 0x03070105u : 0x06020400u, selB = hi ? 0x03020706u : 0x05040100u;
-  // chroma strips: lanes 0..31 = plane*16 + blk*4 + sq
-  const int cpl = (lane >> 4) & 1, ccb = (lane >> 2) & 3, ccx = ccb & 1, ccy = ccb >> 1;
-  // Intra16x16 DC: the lanes of block (bx,by) load c[by][bx]; f = A c A = P (H c H) P^T with H the natural
-  // 4-point Hadamard and A row i = H row s(i), s = [0,2,3,1]: block (bx,by) takes g[s(by)][s(bx)].
-  const int dcZZ = (int)((0xFEA9DB83C7426510ull >> (4 * (sby * 4 + sbx))) & 15ull);
-  const int sxx = (0x1320 >> (4 * sbx)) & 3, syy = (0x1320 >> (4 * sby)) & 3;
-  const int dcSrcLane = 4 * (8 * (syy >> 1) + 4 * (sxx >> 1) + 2 * (syy & 1) + (sxx & 1));
-  // mode grid: lanes 0..15 = by*4+bx (raster)
-  const int mbx = lane & 3, mby = (lane >> 2) & 3;
-  const int mzb = 8 * (mby >> 1) + 4 * (mbx >> 1) + 2 * (mby & 1) + (mbx & 1);
-  // Intra4x4 pixel organisation
-  I4Lane L4;
-  {
-    const int li = lane & 15, g = (lane >> 4) & 1;
-    const int ia = min(li, 12), ib = min(li, 8);
-    L4.li = li;
-    L4.grp1 = g != 0;
-    // E[i]: i <= 3 left column (x -1, y 3-i); i == 4 corner; i >= 5 top row (x i-5, y -1).
-    // group 1 works on block (bx-2, by+1): +4 rows, -8 columns = +120 bytes.
-    L4.eoffA = (ia <= 3 ? (3 - ia) * 32 - 1 : (ia == 4 ? -33 : -32 + (ia - 5))) + 120 * g;
-    L4.eoffB = (ib <= 3 ? (3 - ib) * 32 - 1 : (ib == 4 ? -33 : -32 + (ib - 5))) + 120 * g;
-    L4.wrOff = (li >> 2) * 32 + (li & 3) + 120 * g;
-    L4.resOff = li + 32 * g;
-    L4.gb4 = (lane & ~15) * 4;
-  }
+  __syncthreads();  // the only workgroup-level synchronisation: waves are independent from here on
 
   const size_t frameBytes = (size_t)W * H * 384;
   const int pitchY = W * 16, pitchC = W * 8;
-  const int G = gridDim.x;
-  const int nfLocal = (P.n_frames - (int)blockIdx.x + G - 1) / G;
-  const int totalRows = nfLocal * H;
+  const unsigned totalTasks = (unsigned)P.n_frames * (unsigned)H;
 
-  for (int Rg = wave; Rg < totalRows; Rg += NW) {
-    const int it = Rg / H;
-    const int r = Rg - it * H;
-    const int f = blockIdx.x + it * G;
-    const int slot = Rg % NW;
-    const int slotUp = (Rg + NW - 1) % NW;
+  for (;;) {
+    // ---- claim the next macroblock row ---------------------------------------------------------
+    unsigned task = 0;
+    if (lane0 == 0) task = atomicAdd(taskCounter, 1u);
+    task = (unsigned)rfl((int)task);
+    if (task >= totalTasks) break;
+    const int r = (int)(task / (unsigned)P.n_frames);
+    const int f = (int)(task - (unsigned)r * (unsigned)P.n_frames);
     const size_t mbBase = (size_t)f * W * H + (size_t)r * W;
     uint8_t* planeY = yuv + (size_t)f * frameBytes;
     uint8_t* planeCb = planeY + (size_t)W * H * 256;
     uint8_t* planeCr = planeCb + (size_t)W * H * 64;
-    uint8_t* myLineY = lineY + slot * lineY_stride + 16;
-    const uint8_t* upLineY = lineY + slotUp * lineY_stride + 16;
-    uint8_t* myLineC = lineC + slot * 2 * lineC_stride + 16;
-    const uint8_t* upLineC = lineC + slotUp * 2 * lineC_stride + 16;
-    uint8_t* myLineM = lineM + slot * W * 4;
-    const uint8_t* upLineM = lineM + slotUp * W * 4;
+    unsigned* myProg = rowProg + (size_t)f * H + r;
+    const unsigned* upProg = myProg - 1;
+    unsigned* myModes = rowModes + mbBase;
     const bool mbB = r > 0;
-
-    if (lane == 0)
-      __hip_atomic_store(&prog[slot], ((unsigned)(Rg + 1) << 12), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned upDone = 0;  // what we know of the row above's progress
 
     // coefficients of macroblock 0 of the row: global -> LDS DMA, 48 lanes x 16 B
     const int16_t* crow = coeffs + mbBase * 384;
-    if (lane < 48) __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + lane * 8), (lds_void*)ws->coef, 16, 0, 0);
+    if (lane0 < 48) __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + lane0 * 8), (lds_void*)ws->coef, 16, 0, 0);
     uint4 desc = *(const uint4*)(mbs + mbBase);
 
     int Mprev = 2;  // derived modes of the macroblock to the left, on the 4x4 grid (lanes 0..15)
 
     for (int mx = 0; mx < W; mx++) {
+      // Per-lane constants are recomputed per macroblock from an opaque lane id: keeping them (and the
+      // dozens of LDS addresses derived from them) live across the loop costs ~90 VGPRs, i.e. half the
+      // occupancy; recomputing costs a few dozen VALU.
+      asm volatile("" : "+v"(lane));
+      // "strip" organisation: 4 lanes per 4x4 block, sb = blkIdx (z-order), sq = row (then column) in the block
+      const int sq = lane & 3, sb = lane >> 2;
+      const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
+      const int sbx = ((sb >> 1) & 2) | (sb & 1), sby = ((sb >> 2) & 2) | ((sb >> 1) & 1);
+      const unsigned zz = sq == 0 ? 0x6510u : sq == 1 ? 0xC742u : sq == 2 ? 0xDB83u : 0xFEA9u;
+      const unsigned selA = odd ? 0x03070105u : 0x06020400u, selB = hi ? 0x03020706u : 0x05040100u;
+      // chroma strips: lanes 0..31 = plane*16 + blk*4 + sq
+      const int cpl = (lane >> 4) & 1, ccb = (lane >> 2) & 3, ccx = ccb & 1, ccy = ccb >> 1;
+      // mode grid: lanes 0..15 = by*4+bx (raster)
+      const int mbx = lane & 3, mby = (lane >> 2) & 3;
+      const int mzb = 8 * (mby >> 1) + 4 * (mbx >> 1) + 2 * (mby & 1) + (mbx & 1);
+
       const unsigned d0 = rfl(desc.x), d1 = rfl(desc.y), d2 = rfl(desc.z), d3 = rfl(desc.w);
       int kind = d0 & 0xff;
       const int i16mode = (d0 >> 8) & 0xff;
@@ -350,8 +344,10 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       const bool mbA = mx > 0, mbC = mbB && (mx + 1 < W);
       const int qpc0 = qpc_of(qp, P.cqo_cb), qpc1 = qpc_of(qp, P.cqo_cr);
 
-      // the DMA of this macroblock's coefficients must have landed
+      // Everything this wave issued so far has completed: the DMA of this macroblock's coefficients has
+      // landed, and the pixel / mode stores of macroblock mx-1 have been written through -> publish it.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (mx > 0 && lane == 0) st_sc1(myProg, (unsigned)mx);
       WAVE_SYNC();
 
       // ================= residuals (need no neighbour: done before waiting for the row above) =====
@@ -381,7 +377,12 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         if (kind == 0) {
           residual4x4_quad(ws->coef, sb * 16, zz, false, 0, qp, ls4, sq, odd, hi, rl);
         } else if (kind == 2) {
-          // Intra16x16 luma DC: 8.5.10 (pred16x16.rs:428-482)
+          // Intra16x16 luma DC: 8.5.10 (pred16x16.rs:428-482). The lanes of block (bx,by) load c[by][bx];
+          // f = A c A = P (H c H) P^T with H the natural 4-point Hadamard and A row i = H row s(i),
+          // s = [0,2,3,1]: block (bx,by) takes g[s(by)][s(bx)].
+          const int dcZZ = (int)((0xFEA9DB83C7426510ull >> (4 * (sby * 4 + sbx))) & 15ull);
+          const int sxx = (0x1320 >> (4 * sbx)) & 3, syy = (0x1320 >> (4 * sby)) & 3;
+          const int dcSrcLane = 4 * (8 * (syy >> 1) + 4 * (sxx >> 1) + 2 * (syy & 1) + (sxx & 1));
           int x = ws->coef[dcZZ];
           int o = shfl(x, lane ^ 4);
           x = (sbx & 1) ? o - x : x + o;
@@ -441,18 +442,34 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         desc = *(const uint4*)(mbs + mbBase + mx + 1);
       }
 
-      // ================= wait for the row above ====================================================
-      if (Rg > 0) {
-        const unsigned need = ((unsigned)Rg << 12) | (unsigned)min(mx + 2, W);
-        while (__hip_atomic_load(&prog[slotUp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-          __builtin_amdgcn_s_sleep(1);
+      // ================= wait for the row above, fetch the neighbour window ======================
+      if (mbB) {
+        const unsigned need = (unsigned)min(mx + 2, W);
+        while (upDone < need) {
+          unsigned v = 0;
+          if (lane == 0) v = ld_sc1(upProg);
+          upDone = (unsigned)rfl((int)v);
+          if (upDone < need) __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: keep the loads below the poll
+        // lanes 0..7: Y x = -4..27 of pixel row 16r-1; 8..11: Cb x = -4..11 of row 8r-1; 12..15: Cr; 16: modes
+        if (lane < 17) {
+          const unsigned* src;
+          if (lane < 8) src = (const unsigned*)(planeY + (size_t)(r * 16 - 1) * pitchY + mx * 16 - 4) + lane;
+          else if (lane < 12) src = (const unsigned*)(planeCb + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 8);
+          else if (lane < 16) src = (const unsigned*)(planeCr + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 12);
+          else src = myModes - W + mx;
+          ((unsigned*)ws->up)[lane] = ld_sc1(src);
+        }
+        WAVE_SYNC();
       }
+      const uint8_t* up = ws->up;
 
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366) on lanes 0..31 ====================
       // lane = plane*16 + blk*4 + column sq; pixels (x = 4*ccx + sq, y = 4*ccy + k)
       unsigned cword = 0;  // after the byte transpose: row sq of the block, 4 pixels
       if (lane < 32) {
-        const uint8_t* upc = upLineC + cpl * lineC_stride + mx * 8;
+        const uint8_t* upc = up + UPC(cpl, 0);
         const int x = 4 * ccx + sq;
         int pr[4] = {0, 0, 0, 0};
         if (kind != 3) {
@@ -515,7 +532,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         const int x = 4 * sbx + sq;
         int pr[4] = {0, 0, 0, 0};
         if (i16mode == 0) {
-          if (mbB) pr[0] = pr[1] = pr[2] = pr[3] = upLineY[mx * 16 + x];
+          if (mbB) pr[0] = pr[1] = pr[2] = pr[3] = up[UPY(x)];
         } else if (i16mode == 1) {
           if (mbA) {
             const unsigned lw = *(const unsigned*)&ws->leftY[4 * sby];
@@ -525,7 +542,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         } else if (i16mode == 2) {
           // lanes 0..3: top words, 4..7: left words
           unsigned wv = 0;
-          if (lane < 4) wv = *(const unsigned*)&upLineY[mx * 16 + 4 * lane];
+          if (lane < 4) wv = *(const unsigned*)&up[UPY(4 * lane)];
           else if (lane < 8) wv = *(const unsigned*)&ws->leftY[4 * (lane - 4)];
           int s = (int)sum4(wv);
           s += xor1(s);
@@ -541,14 +558,14 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           // plane (:366-424): lanes 0..7 horizontal terms, 8..15 vertical terms
           const int k = lane & 7;
           int term = 0;
-          if (lane < 8) term = (k + 1) * ((int)upLineY[mx * 16 + 8 + k] - (int)upLineY[mx * 16 + 6 - k]);  // 6-k = -1: corner
+          if (lane < 8) term = (k + 1) * ((int)up[UPY(8 + k)] - (int)up[UPY(6 - k)]);  // 6-k = -1: corner
           else if (lane < 16)
-            term = (k + 1) * ((int)ws->leftY[8 + k] - (k == 7 ? (int)upLineY[mx * 16 - 1] : (int)ws->leftY[6 - k]));
+            term = (k + 1) * ((int)ws->leftY[8 + k] - (k == 7 ? (int)up[UPY(-1)] : (int)ws->leftY[6 - k]));
           term += xor1(term);
           term += xor2(term);
           term += dpp<ROW_SHR(4)>(0, term);
           const int hs = __builtin_amdgcn_readlane(term, 4), vs = __builtin_amdgcn_readlane(term, 12);
-          const int a = 16 * ((int)ws->leftY[15] + (int)upLineY[mx * 16 + 15]);
+          const int a = 16 * ((int)ws->leftY[15] + (int)up[UPY(15)]);
           const int b = (5 * hs + 32) >> 6, c = (5 * vs + 32) >> 6;
           const int base = a + b * (x - 7) + c * (4 * sby - 7) + 16;
 #pragma unroll
@@ -559,9 +576,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         for (int k = 0; k < 4; k++) w |= (unsigned)clip255(pr[k] + rl[k]) << (8 * k);
         yword = quad_transpose_bytes(w, selA, selB);  // row sq of block sb: x = 4*sbx .. +3, y = 4*sby+sq
       } else if (kind == 0 || kind == 1) {
-        // top border of the tile from the ring slot of the row above; the left border is kept up to date
-        if (lane < 25) ws->tileY[TY(lane - 1, -1)] = upLineY[mx * 16 - 1 + lane];
-        const unsigned upM = mbB ? *(const unsigned*)&upLineM[mx * 4] : 0x02020202u;
+        // top border of the tile from the neighbour window; the left border is kept up to date
+        if (lane < 25) ws->tileY[TY(lane - 1, -1)] = up[UPY(lane - 1)];
+        const unsigned upM = mbB ? *(const unsigned*)&up[UPM] : 0x02020202u;
         const int Tb = (int)((upM >> (8 * mbx)) & 0xff);  // meaningful on lanes with mby == 0
         const int Lb = dpp<ROW_SHL(3)>(Mprev, Mprev);     // meaningful on lanes with mbx == 0: left MB's column 3
         if (kind == 0) {
@@ -587,6 +604,21 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
           const int req = (int)((0x217771021ull >> (4 * M)) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
           const int Mp = (req & ~have) != 0 ? 9 : M;
+          // Intra4x4 pixel organisation (lanes 0..31): 16 lanes per block, two blocks per step
+          I4Lane L4;
+          {
+            const int li = lane & 15, g = (lane >> 4) & 1;
+            const int ia = min(li, 12), ib = min(li, 8);
+            L4.li = li;
+            L4.grp1 = g != 0;
+            // E[i]: i <= 3 left column (x -1, y 3-i); i == 4 corner; i >= 5 top row (x i-5, y -1).
+            // group 1 works on block (bx-2, by+1): +4 rows, -8 columns = +120 bytes.
+            L4.eoffA = (ia <= 3 ? (3 - ia) * 32 - 1 : (ia == 4 ? -33 : -32 + (ia - 5))) + 120 * g;
+            L4.eoffB = (ib <= 3 ? (3 - ib) * 32 - 1 : (ib == 4 ? -33 : -32 + (ib - 5))) + 120 * g;
+            L4.wrOff = (li >> 2) * 32 + (li & 3) + 120 * g;
+            L4.resOff = li + 32 * g;
+            L4.gb4 = (lane & ~15) * 4;
+          }
           WAVE_SYNC();
           // ---- pixels: 10-step 2:1 block wavefront ------------------------------------------------
           i4_step<0>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
@@ -674,58 +706,76 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
 
       // ================= write-out ==================================================================
-      // chroma: lanes 0..31, row strip (plane cpl, row 4*ccy+sq, x = 4*ccx..+3)
-      if (lane < 32) {
+      // The bottom pixel line of the row (luma y = 15, chroma y = 7) and the bottom-row modes are what the
+      // row below reads: they are stored write-through (sc1). Everything else is a plain write-back store.
+      if (lane < 32) {  // chroma: row strip (plane cpl, row 4*ccy+sq, x = 4*ccx..+3)
         const int cyy = 4 * ccy + sq;
         uint8_t* pc = cpl ? planeCr : planeCb;
-        *(unsigned*)(pc + (size_t)(r * 8 + cyy) * pitchC + mx * 8 + 4 * ccx) = cword;
-        if (cyy == 7) *(unsigned*)(myLineC + cpl * lineC_stride + mx * 8 + 4 * ccx) = cword;
+        unsigned* dst = (unsigned*)(pc + (size_t)(r * 8 + cyy) * pitchC + mx * 8 + 4 * ccx);
+        if (cyy == 7) st_sc1(dst, cword);
+        else *dst = cword;
         if (ccx == 1) ws->leftC[cpl][cyy] = (uint8_t)(cword >> 24);
       }
-      if (kind == 0 || kind == 1) {
-        const int y = lane >> 2, xw = (lane & 3) * 4;
-        const unsigned w = *(const unsigned*)&ws->tileY[TY(xw, y)];
-        *(unsigned*)(planeY + (size_t)(r * 16 + y) * pitchY + mx * 16 + xw) = w;
-        if (y == 15) *(unsigned*)(myLineY + mx * 16 + xw) = w;
-        if ((lane & 3) == 3) {
+      {
+        int y, xw;
+        unsigned w;
+        if (kind == 0 || kind == 1) {
+          y = lane >> 2;
+          xw = (lane & 3) * 4;
+          w = *(const unsigned*)&ws->tileY[TY(xw, y)];
+        } else {
+          y = 4 * sby + sq;
+          xw = 4 * sbx;
+          w = yword;
+        }
+        unsigned* dst = (unsigned*)(planeY + (size_t)(r * 16 + y) * pitchY + mx * 16 + xw);
+        if (y == 15) st_sc1(dst, w);
+        else *dst = w;
+        if (xw == 12) {
           ws->leftY[y] = (uint8_t)(w >> 24);
           ws->tileY[TY(-1, y)] = (uint8_t)(w >> 24);
         }
-      } else {
-        const int y = 4 * sby + sq;
-        *(unsigned*)(planeY + (size_t)(r * 16 + y) * pitchY + mx * 16 + 4 * sbx) = yword;
-        if (y == 15) *(unsigned*)(myLineY + mx * 16 + 4 * sbx) = yword;
-        if (sbx == 3) {
-          ws->leftY[y] = (uint8_t)(yword >> 24);
-          ws->tileY[TY(-1, y)] = (uint8_t)(yword >> 24);
-        }
       }
-      // bottom-row modes for the row below, whole grid for the macroblock to the right
-      if (lane >= 12 && lane < 16) myLineM[mx * 4 + lane - 12] = (uint8_t)Mcur;
+      // bottom-row modes (grid lanes 12..15) for the row below; the whole grid for the macroblock to the right
+      {
+        const unsigned m4 = (unsigned)__builtin_amdgcn_readlane(Mcur, 12) | ((unsigned)__builtin_amdgcn_readlane(Mcur, 13) << 8) |
+                            ((unsigned)__builtin_amdgcn_readlane(Mcur, 14) << 16) |
+                            ((unsigned)__builtin_amdgcn_readlane(Mcur, 15) << 24);
+        if (lane == 0) st_sc1(myModes + mx, m4);
+      }
       Mprev = Mcur;
       WAVE_SYNC();
-      // ================= publish progress ===========================================================
-      if (lane == 0)
-        __hip_atomic_store(&prog[slot], ((unsigned)(Rg + 1) << 12) | (unsigned)(mx + 1), __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    // the row is complete once its last stores have been written through
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane0 == 0) st_sc1(myProg, (unsigned)W);
   }
 }
 
-size_t recon_lds_bytes(int W, int NW) {
-  const size_t lineY = (size_t)W * 16 + 48, lineC = (size_t)W * 8 + 32;
-  const size_t lineM = ((size_t)NW * W * 4 + 15) & ~(size_t)15;
-  return 1984 + (size_t)NW * lineY + (size_t)NW * 2 * lineC + lineM + (size_t)NW * sizeof(WaveScratch);
+size_t recon_lds_bytes(int wavesPerBlock) { return 1920 + (size_t)wavesPerBlock * sizeof(WaveScratch); }
+
+size_t recon_workspace_bytes(int W, int H, int n_frames) {
+  // [task counter | pad to 256] [row progress: n_frames*H u32 | pad to 256] [bottom-row modes: n_mbs u32]
+  const size_t prog = (((size_t)n_frames * H * 4) + 255) & ~(size_t)255;
+  return 256 + prog + (size_t)n_frames * W * H * 4;
+}
+
+static size_t prog_bytes(const KParams& P) { return (((size_t)P.n_frames * P.H * 4) + 255) & ~(size_t)255; }
+
+// the task counter and the row-progress words start every launch at zero (the modes need no reset:
+// every word is written before it is read)
+hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, hipStream_t stream) {
+  return hipMemsetAsync(d_workspace, 0, 256 + prog_bytes(P), stream);
 }
 
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                        int NW, int grid, hipStream_t stream) {
-  const size_t ldsBytes = recon_lds_bytes(P.W, NW);
-  hipError_t e = hipFuncSetAttribute((const void*)recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)ldsBytes);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(recon_kernel, dim3(grid), dim3(NW * 64), ldsBytes, stream, P, (const dryv_mb_desc*)d_mbs,
-                     (const int16_t*)d_coeffs, (uint8_t*)d_yuv, d_status);
+                        void* d_workspace, int grid, hipStream_t stream) {
+  const int wavesPerBlock = 4;
+  const size_t ldsBytes = recon_lds_bytes(wavesPerBlock);
+  unsigned char* wsb = (unsigned char*)d_workspace;
+  hipLaunchKernelGGL(recon_kernel, dim3(grid), dim3(wavesPerBlock * 64), ldsBytes, stream, P,
+                     (const dryv_mb_desc*)d_mbs, (const int16_t*)d_coeffs, (uint8_t*)d_yuv, d_status,
+                     (unsigned*)(wsb + 256), (unsigned*)(wsb + 256 + prog_bytes(P)), (unsigned*)wsb);
   return hipGetLastError();
 }
 
