@@ -73,7 +73,10 @@ struct WaveScratch {
   int16_t coef[384];  // the macroblock's coefficient lists as they arrive (zig-zag order); DMA target
   union {
     struct {
-      int16_t resB[256];       // Intra4x4 residual [by*4+bx][y*4+x]; Intra8x8 residual [y*16+x]
+      union {
+        unsigned resTe[256];   // Intra4x4: per pixel [by*4+bx][y*4+x]: residual (lo 16) | table entry (hi 16)
+        int16_t resB[256];     // Intra8x8 residual [y*16+x]
+      };
       uint8_t tileY[17 * 32];  // luma tile with borders: row 0 = y -1, byte 3 = x -1, bytes 4..27 = x 0..23
     };
     int32_t g8[256];  // 8x8 transform: row-pass output of the four blocks
@@ -188,55 +191,150 @@ __host__ __device__ constexpr int stepByHi(int t) { return (t >> 1) < 3 ? (t >> 
 // top-right 4x4 block decoded before this one inside the macroblock (by > 0): bx even, or (1,2)
 __host__ __device__ constexpr bool trInside(int bx, int by) { return (bx & 1) == 0 || (bx == 1 && by == 2); }
 
-struct I4Lane {      // per-lane constants of the Intra4x4 pixel organisation (lanes 0..31)
-  int eoffA, eoffB;  // E gather offset from the group-0 block origin, top-right available / not
-  int wrOff;         // this lane's pixel offset from the group-0 block origin (tile bytes)
-  int resOff;        // this lane's residual offset from the group-0 block's resB base (int16 units)
-  int gb4;           // 4 * first lane of this 16-lane group
-  int li;            // lane & 15
-  bool grp1;         // lane belongs to group 1
+template <int CTRL>
+__device__ __forceinline__ int dppz(int src) {  // lanes without a source read 0: lets the compiler fold the DPP
+  return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xF, 0xF, true);
+}
+
+// Intra4x4 pixel organisation: lanes 0..31, 16 lanes per block, two blocks (groups) per step.
+// The 16 lanes of a block first hold its reference samples on one line (index i'):
+//   0: L3 (dup) | 1..4: L3..L0 (left column, bottom to top) | 5: corner | 6..13: T0..T7 | 14: T7 (dup) | 15: DC
+// F[i'] = (E[i'-1] + 2E[i'] + E[i'+1] + 2) >> 2 and G[i'] = (E[i'] + E[i'+1] + 1) >> 1 come from DPP row
+// shifts; the duplicated ends give the reference's (a + 3b + 2) >> 2 corner cases for free.
+struct I4Lane {
+  int pEB;       // LDS byte address of this lane's sample relative to the group-0 block origin, no top-right block
+  int dEA;       // ... + dEA when the top-right block exists (lanes 10..15 then read T4..T7 instead of T3)
+  int pW;        // LDS byte address of this lane's pixel relative to the group-0 block origin
+  int pRT;       // LDS byte address of this lane's resTe word relative to the group-0 block's first word
+  int gb4;       // 4 * first lane of this 16-lane group
+  bool grp1, is15;
 };
 
 // One step of the Intra4x4 block wavefront (8.3.1.2, pred4x4.rs:10-360), statically scheduled.
-template <int T>
-__device__ __forceinline__ void i4_step(WaveScratch* ws, const I4Lane& L, const uint16_t* t4x, int Mp, bool mbA,
-                                        bool mbB, bool mbC, int lane) {
+// INTERIOR: macroblocks A, B and C all exist, every availability test folds away.
+template <int T, bool INTERIOR>
+__device__ __forceinline__ void i4_step(const I4Lane& L, bool mbA, bool mbB, bool mbC, int lane) {
   constexpr int by0 = stepByLo(T), bx0 = T - 2 * by0;
   constexpr bool two = by0 + 1 <= stepByHi(T);
   constexpr int bx1 = two ? bx0 - 2 : bx0, by1 = two ? by0 + 1 : by0;  // group-1 block
-  const bool act = two ? lane < 32 : lane < 16;
-  if (!act) return;
+  constexpr int oTile = TY(4 * bx0, 4 * by0);                          // tile byte offset of the block origin
+  constexpr int oRT = (by0 * 4 + bx0) * 64;                            // byte offset of the block's resTe words
+  if (!(two ? lane < 32 : lane < 16)) return;
+  typedef __attribute__((address_space(3))) const uint8_t* lds_u8p;
+  typedef __attribute__((address_space(3))) const unsigned* lds_u32p;
+  typedef __attribute__((address_space(3))) uint8_t* lds_u8w;
   // top-right availability per group
-  const bool tr0 = by0 > 0 ? trInside(bx0, by0) : (bx0 < 3 ? mbB : mbC);
-  const bool tr1 = two ? trInside(bx1, by1) : tr0;
-  const bool tr = L.grp1 ? tr1 : tr0;
-  const int eoff = tr ? L.eoffA : L.eoffB;
-  const int E = ws->tileY[TY(4 * bx0, 4 * by0) + eoff];
-  // this block's mode (already derived; 9 = "reference samples missing": zero prediction, quirk Q4)
-  const int mode = shfl(Mp, (by0 * 4 + bx0) + (L.grp1 ? 2 : 0));
-  const int te = t4x[mode * 16 + L.li];
-  const int res = ws->resB[(by0 * 4 + bx0) * 16 + L.resOff];
-  // filtered lines: F[i] = (E[i-1] + 2E[i] + E[i+1] + 2) >> 2, G[i] = (E[i] + E[i+1] + 1) >> 1, ends replicated
-  const int El = dpp<ROW_SHR(1)>(E, E), Er = dpp<ROW_SHL(1)>(E, E);
-  const int F = (El + 2 * E + Er + 2) >> 2;
-  const int G = (E + Er + 1) >> 1;
-  // DC (pred4x4.rs:116-167): E[0..3] = left column, E[5..8] = top row
-  const int s1 = E + Er;
-  const int s2 = s1 + dpp<ROW_SHL(2)>(s1, s1);
-  const int sumL = dpp<ROW_SHR(15)>(s2, s2), sumT = dpp<ROW_SHR(10)>(s2, s2);  // valid on lane 15
-  const bool topAv = L.grp1 ? (by1 > 0 || mbB) : (by0 > 0 || mbB);
-  const bool leftAv = L.grp1 ? (bx1 > 0 || mbA) : (bx0 > 0 || mbA);
+  const bool tr0 = by0 > 0 ? trInside(bx0, by0) : (INTERIOR ? true : (bx0 < 3 ? mbB : mbC));
+  constexpr bool tr1 = trInside(bx1, by1);
+  // (arithmetic rather than a select between two struct fields: the latter becomes an indexed scratch load)
+  const int trMask = (L.grp1 ? tr1 : tr0) ? -1 : 0;
+  const int pE = L.pEB + (L.dEA & trMask);
+  const int E = *(lds_u8p)(uintptr_t)(unsigned)(pE + oTile);
+  const unsigned rt = *(lds_u32p)(uintptr_t)(unsigned)(L.pRT + oRT);
+  const int a = E + dppz<ROW_SHL(1)>(E);  // E[i] + E[i+1]
+  const int b = E + dppz<ROW_SHR(1)>(E);  // E[i] + E[i-1]
+  const int F = (a + b + 2) >> 2;
+  const int G = (a + 1) >> 1;
+  // DC (pred4x4.rs:116-167): left column = E[1..4], top row = E[6..9]
+  const int s2 = a + dppz<ROW_SHL(2)>(a);
+  const int sumL = dppz<ROW_SHR(14)>(s2), sumT = dppz<ROW_SHR(9)>(s2);  // meaningful on lane 15
   int dc;
-  if (topAv && leftAv) dc = (sumT + sumL + 4) >> 3;
-  else if (leftAv) dc = (sumL + 2) >> 2;
-  else if (topAv) dc = (sumT + 2) >> 2;
-  else dc = 128;
-  // lane 15 carries the DC value, lane 14 a zero (table rows 2 and 9 point there)
-  const int E2 = L.li == 15 ? dc : (L.li == 14 ? 0 : E);
-  const int packed = E2 | (F << 8) | (G << 16);
-  const int got = __builtin_amdgcn_ds_bpermute(L.gb4 + (te & 0xff), packed);
-  const int pred = (got >> (te >> 8)) & 0xff;
-  ws->tileY[TY(4 * bx0, 4 * by0) + L.wrOff] = (uint8_t)clip255(pred + res);
+  if (INTERIOR) {
+    dc = (sumT + sumL + 4) >> 3;
+  } else {
+    const bool topAv = L.grp1 ? (by1 > 0 || mbB) : (by0 > 0 || mbB);
+    const bool leftAv = L.grp1 ? (bx1 > 0 || mbA) : (bx0 > 0 || mbA);
+    dc = (topAv && leftAv) ? (sumT + sumL + 4) >> 3 : leftAv ? (sumL + 2) >> 2 : topAv ? (sumT + 2) >> 2 : 128;
+  }
+  const int packed = (L.is15 ? dc : E) | (F << 8) | (G << 16);  // byte 3 stays 0: the "no prediction" entry
+  const int got = __builtin_amdgcn_ds_bpermute(L.gb4 + (int)((rt >> 16) & 0xff), packed);
+  const int pred = (got >> (rt >> 24)) & 0xff;
+  *(lds_u8w)(uintptr_t)(unsigned)(L.pW + oTile) = (uint8_t)clip255(pred + (int)(int16_t)(rt & 0xffff));
+}
+
+// Intra4x4 macroblock: mode derivation (8.3.1.1), residual/table packing, the 10-step pixel wavefront.
+template <bool INTERIOR>
+__device__ __forceinline__ int i4_macroblock(WaveScratch* ws, const uint16_t* t4x, const int rl[4], int lane, int Tb, int Lb,
+                                             unsigned prevFlags, unsigned long long remBits, bool mbA, bool mbB,
+                                             bool mbC) {
+  // mode grid: lanes 0..15 = by*4+bx (raster)
+  const int mbx = lane & 3, mby = (lane >> 2) & 3;
+  const int mzb = 8 * (mby >> 1) + 4 * (mbx >> 1) + 2 * (mby & 1) + (mbx & 1);
+  const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
+  const bool prev = ((prevFlags >> mzb) & 1u) != 0;
+  const bool unav = INTERIOR ? false : ((mbx == 0 && !mbA) || (mby == 0 && !mbB));
+  // ---- Intra4x4PredMode (pred4x4.rs:363-427) as a relaxation over the block grid: after sweep k every
+  // block with bx + by <= k is final
+  int M = 2;
+#pragma unroll
+  for (int itr = 0; itr < 7; itr++) {
+    int Am = dpp<QUAD(0, 0, 1, 2)>(M, M);
+    if (mbx == 0) Am = Lb;
+    const int Bm = dpp<ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
+    const int pm = unav ? 2 : min(Am, Bm);
+    M = prev ? pm : (rem < pm ? rem : rem + 1);
+  }
+  int Mp = M;
+  if (!INTERIOR) {
+    // quirk Q4: a mode whose reference samples are missing leaves the zero-initialised prediction
+    const bool topAv = mby > 0 || mbB, leftAv = mbx > 0 || mbA;
+    const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
+    const int req = (int)((0x217771021ull >> (4 * M)) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
+    if ((req & ~have) != 0) Mp = 9;
+  }
+  // ---- residual + table entry per pixel. Strip lane (block sb, column sq) owns pixels (x = sq, y = 0..3)
+  {
+    const int sq = lane & 3, sb = lane >> 2;
+    const int sbx = ((sb >> 1) & 2) | (sb & 1), sby = ((sb >> 2) & 2) | ((sb >> 1) & 1);
+    const int g = sby * 4 + sbx;
+    const int mode = shfl(Mp, g);
+    const uint2 te = *(const uint2*)&t4x[mode * 16 + sq * 4];  // entries for (x = sq, y = 0..3)
+    unsigned* dst = &ws->resTe[g * 16 + sq];
+    dst[0] = __builtin_amdgcn_perm(te.x, (unsigned)rl[0], 0x05040100u);   // te.x lo16 : rl lo16
+    dst[4] = __builtin_amdgcn_perm(te.x, (unsigned)rl[1], 0x07060100u);   // te.x hi16 : rl lo16
+    dst[8] = __builtin_amdgcn_perm(te.y, (unsigned)rl[2], 0x05040100u);
+    dst[12] = __builtin_amdgcn_perm(te.y, (unsigned)rl[3], 0x07060100u);
+  }
+  // ---- per-lane addresses of the pixel organisation
+  I4Lane L;
+  {
+    const int li = lane & 15, g = (lane >> 4) & 1;
+    auto eo = [](int i) {  // sample i' of the line, relative to the block origin in the tile
+      return i <= 4 ? (3 - max(i - 1, 0)) * 32 - 1 : (i == 5 ? -33 : -32 + min(i - 6, 7));
+    };
+    const int tileBase = (int)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ws->tileY;
+    const int rtBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned*)ws->resTe;
+    // group 1 works on block (bx-2, by+1): +4 tile rows, -8 columns = +120 bytes; +2 blocks = +128 bytes of resTe
+    L.pEB = tileBase + eo(min(li, 9)) + 120 * g;  // no top-right block: T4..T7 := T3
+    L.dEA = eo(li) - eo(min(li, 9));
+    L.pW = tileBase + (li >> 2) * 32 + (li & 3) + 120 * g;
+    L.pRT = rtBase + 4 * li + 128 * g;
+    L.gb4 = (lane & ~15) * 4;
+    L.grp1 = g != 0;
+    L.is15 = li == 15;
+  }
+  WAVE_SYNC();
+  i4_step<0, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<1, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<2, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<3, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<4, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<5, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<6, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<7, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<8, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  i4_step<9, INTERIOR>(L, mbA, mbB, mbC, lane);
+  WAVE_SYNC();
+  return M;
 }
 
 // relaxed agent-scope accesses: global_load/store ... sc1 (served by / written through L2, bypassing L1)
@@ -247,6 +345,20 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Diagnostic build only (-DDRYV_PHASE_PROFILE, tools/phase_profile.py): per-wave cycle sums per phase,
+// written to a buffer of their own. The shipped library contains none of this.
+#ifdef DRYV_PHASE_PROFILE
+#define PHASE_STAMP(i)                                                   \
+  do {                                                                   \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                  \
+    phaseAcc[i] += now_ - phaseT;                                        \
+    phaseT = now_;                                                       \
+  } while (0)
+#else
+#define PHASE_STAMP(i) do { } while (0)
+#endif
+
 #define UPY(k) (4 + (k))        // byte index in WaveScratch::up of luma sample x = k of the row above
 #define UPC(pl, k) (36 + 16 * (pl) + (k))
 #define UPM 64
@@ -254,7 +366,11 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
 __global__ void __launch_bounds__(256, 8)
 recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_t* __restrict__ coeffs,
              uint8_t* __restrict__ yuv, unsigned* __restrict__ status, unsigned* __restrict__ rowProg,
-             unsigned* __restrict__ rowModes, unsigned* __restrict__ taskCounter) {
+             unsigned* __restrict__ rowModes, unsigned* __restrict__ taskCounter
+#ifdef DRYV_PHASE_PROFILE
+             , unsigned long long* __restrict__ phaseOut
+#endif
+             ) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane0 = threadIdx.x & 63;
   int lane = lane0;
@@ -272,10 +388,16 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   for (int i = threadIdx.x; i < 96; i += blockDim.x) ls4[i] = P.ls4[i];
   for (int i = threadIdx.x; i < 384; i += blockDim.x) ls8[i] = P.ls8[i];
   for (int i = threadIdx.x; i < 160; i += blockDim.x) {
+    // t4x[mode][x][y]: low byte = 4 * lane index of the sample on the line (shifted by one, see I4Lane),
+    // high byte = bit offset of E / F / G in the packed word; 24 = the always-zero byte ("no prediction")
+    const int mode = i >> 4, x = (i >> 2) & 3, y = i & 3;
     uint16_t v;
-    if (i >= 144) v = (uint16_t)(14 * 4);                // row 9: lane 14 holds 0
-    else if (i >= 32 && i < 48) v = (uint16_t)(15 * 4);  // row 2 (DC): lane 15 holds the DC value
-    else v = (uint16_t)(((P.t4[i] & 31) * 4) | (((P.t4[i] >> 5) * 8) << 8));
+    if (mode == 9) v = (uint16_t)(24 << 8);
+    else if (mode == 2) v = (uint16_t)(15 * 4);
+    else {
+      const int e = P.t4[mode * 16 + y * 4 + x];
+      v = (uint16_t)((((e & 31) + 1) * 4) | (((e >> 5) * 8) << 8));
+    }
     t4x[i] = v;
   }
   for (int i = threadIdx.x; i < 576; i += blockDim.x) t8[i] = P.t8[i];
@@ -285,12 +407,18 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   const size_t frameBytes = (size_t)W * H * 384;
   const int pitchY = W * 16, pitchC = W * 8;
   const unsigned totalTasks = (unsigned)P.n_frames * (unsigned)H;
+#ifdef DRYV_PHASE_PROFILE
+  unsigned long long phaseAcc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long phaseT = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
 
   for (;;) {
     // ---- claim the next macroblock row ---------------------------------------------------------
     unsigned task = 0;
     if (lane0 == 0) task = atomicAdd(taskCounter, 1u);
     task = (unsigned)rfl((int)task);
+    PHASE_STAMP(0);  // claim
     if (task >= totalTasks) break;
     const int r = (int)(task / (unsigned)P.n_frames);
     const int f = (int)(task - (unsigned)r * (unsigned)P.n_frames);
@@ -346,8 +474,25 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 
       // Everything this wave issued so far has completed: the DMA of this macroblock's coefficients has
       // landed, and the pixel / mode stores of macroblock mx-1 have been written through -> publish it.
+      PHASE_STAMP(1);  // record decode, constants
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PHASE_STAMP(2);  // wait for DMA + previous stores
       if (mx > 0 && lane == 0) st_sc1(myProg, (unsigned)mx);
+      // Row above: start its progress poll now, and -- when what we already know of its progress covers this
+      // macroblock -- the loads of the neighbour window too; both L2 round trips then hide under the residuals.
+      const unsigned need = (unsigned)min(mx + 2, W);
+      const bool winEarly = mbB && upDone >= need;
+      unsigned pollv = 0, winv = 0;
+      // lanes 0..7: Y x = -4..27 of pixel row 16r-1; 8..11: Cb x = -4..11 of row 8r-1; 12..15: Cr; 16: modes
+      const unsigned* winSrc;
+      if (lane < 8) winSrc = (const unsigned*)(planeY + (size_t)(r * 16 - 1) * pitchY + mx * 16 - 4) + lane;
+      else if (lane < 12) winSrc = (const unsigned*)(planeCb + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 8);
+      else if (lane < 16) winSrc = (const unsigned*)(planeCr + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 12);
+      else winSrc = myModes - W + mx;
+      if (mbB) {
+        if (winEarly && lane < 17) winv = ld_sc1(winSrc);
+        if (lane == 0 && upDone < (unsigned)W) pollv = ld_sc1(upProg);
+      }
       WAVE_SYNC();
 
       // ================= residuals (need no neighbour: done before waiting for the row above) =====
@@ -434,6 +579,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
       WAVE_SYNC();
 
+      PHASE_STAMP(3);  // residuals
       // the coefficient buffer is free again: start the DMA of the next macroblock and fetch its record
       if (mx + 1 < W) {
         if (lane < 48)
@@ -444,26 +590,21 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 
       // ================= wait for the row above, fetch the neighbour window ======================
       if (mbB) {
-        const unsigned need = (unsigned)min(mx + 2, W);
+        upDone = max(upDone, (unsigned)rfl((int)pollv));
         while (upDone < need) {
           unsigned v = 0;
           if (lane == 0) v = ld_sc1(upProg);
           upDone = (unsigned)rfl((int)v);
           if (upDone < need) __builtin_amdgcn_s_sleep(2);
         }
+        PHASE_STAMP(4);  // poll the row above
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: keep the loads below the poll
-        // lanes 0..7: Y x = -4..27 of pixel row 16r-1; 8..11: Cb x = -4..11 of row 8r-1; 12..15: Cr; 16: modes
-        if (lane < 17) {
-          const unsigned* src;
-          if (lane < 8) src = (const unsigned*)(planeY + (size_t)(r * 16 - 1) * pitchY + mx * 16 - 4) + lane;
-          else if (lane < 12) src = (const unsigned*)(planeCb + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 8);
-          else if (lane < 16) src = (const unsigned*)(planeCr + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 12);
-          else src = myModes - W + mx;
-          ((unsigned*)ws->up)[lane] = ld_sc1(src);
-        }
+        if (!winEarly && lane < 17) winv = ld_sc1(winSrc);
+        if (lane < 17) ((unsigned*)ws->up)[lane] = winv;
         WAVE_SYNC();
       }
       const uint8_t* up = ws->up;
+      PHASE_STAMP(5);  // neighbour window fetch
 
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366) on lanes 0..31 ====================
       // lane = plane*16 + blk*4 + column sq; pixels (x = 4*ccx + sq, y = 4*ccy + k)
@@ -524,6 +665,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         cword = quad_transpose_bytes(w, selA, selB);  // lane sq now holds row sq: pixels x = 4*ccx .. +3
       }
 
+      PHASE_STAMP(6);  // chroma prediction
       // ================= luma ======================================================================
       unsigned yword = 0;  // row strip of this lane's block, 4 pixels (kinds 2 and 3)
       int Mcur = 2;        // derived modes on the 4x4 grid (lanes 0..15)
@@ -582,65 +724,8 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         const int Tb = (int)((upM >> (8 * mbx)) & 0xff);  // meaningful on lanes with mby == 0
         const int Lb = dpp<ROW_SHL(3)>(Mprev, Mprev);     // meaningful on lanes with mbx == 0: left MB's column 3
         if (kind == 0) {
-          // residuals to LDS for the pixel organisation: resB[by*4+bx][y*4+x]
-#pragma unroll
-          for (int k = 0; k < 4; k++) ws->resB[(sby * 4 + sbx) * 16 + k * 4 + sq] = (int16_t)rl[k];
-          // ---- Intra4x4PredMode: 8.3.1.1 (pred4x4.rs:363-427) as a relaxation over the block grid
-          const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
-          const bool prev = ((prevFlags >> mzb) & 1u) != 0;
-          const bool unav = (mbx == 0 && !mbA) || (mby == 0 && !mbB);
-          int M = 2;
-#pragma unroll
-          for (int itr = 0; itr < 7; itr++) {
-            int Am = dpp<QUAD(0, 0, 1, 2)>(M, M);
-            if (mbx == 0) Am = Lb;
-            const int Bm = dpp<ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
-            const int pm = unav ? 2 : min(Am, Bm);
-            M = prev ? pm : (rem < pm ? rem : rem + 1);
-          }
-          Mcur = M;
-          // quirk Q4: a mode whose reference samples are missing leaves the zero-initialised prediction
-          const bool topAv = mby > 0 || mbB, leftAv = mbx > 0 || mbA;
-          const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
-          const int req = (int)((0x217771021ull >> (4 * M)) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
-          const int Mp = (req & ~have) != 0 ? 9 : M;
-          // Intra4x4 pixel organisation (lanes 0..31): 16 lanes per block, two blocks per step
-          I4Lane L4;
-          {
-            const int li = lane & 15, g = (lane >> 4) & 1;
-            const int ia = min(li, 12), ib = min(li, 8);
-            L4.li = li;
-            L4.grp1 = g != 0;
-            // E[i]: i <= 3 left column (x -1, y 3-i); i == 4 corner; i >= 5 top row (x i-5, y -1).
-            // group 1 works on block (bx-2, by+1): +4 rows, -8 columns = +120 bytes.
-            L4.eoffA = (ia <= 3 ? (3 - ia) * 32 - 1 : (ia == 4 ? -33 : -32 + (ia - 5))) + 120 * g;
-            L4.eoffB = (ib <= 3 ? (3 - ib) * 32 - 1 : (ib == 4 ? -33 : -32 + (ib - 5))) + 120 * g;
-            L4.wrOff = (li >> 2) * 32 + (li & 3) + 120 * g;
-            L4.resOff = li + 32 * g;
-            L4.gb4 = (lane & ~15) * 4;
-          }
-          WAVE_SYNC();
-          // ---- pixels: 10-step 2:1 block wavefront ------------------------------------------------
-          i4_step<0>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<1>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<2>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<3>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<4>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<5>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<6>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<7>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<8>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
-          i4_step<9>(ws, L4, t4x, Mp, mbA, mbB, mbC, lane);
-          WAVE_SYNC();
+          if (mbA && mbC) Mcur = i4_macroblock<true>(ws, t4x, rl, lane, Tb, Lb, prevFlags, remBits, true, true, true);
+          else Mcur = i4_macroblock<false>(ws, t4x, rl, lane, Tb, Lb, prevFlags, remBits, mbA, mbB, mbC);
         } else {
           // ---- Intra8x8: 8.3.2 (pred8x8.rs:152-764), four serial blocks, one pixel per lane -------
           WAVE_SYNC();
@@ -705,6 +790,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         }
       }
 
+      PHASE_STAMP(7);  // luma prediction
       // ================= write-out ==================================================================
       // The bottom pixel line of the row (luma y = 15, chroma y = 7) and the bottom-row modes are what the
       // row below reads: they are stored write-through (sc1). Everything else is a plain write-back store.
@@ -745,11 +831,19 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
       Mprev = Mcur;
       WAVE_SYNC();
+      PHASE_STAMP(8);  // write-out
     }
     // the row is complete once its last stores have been written through
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane0 == 0) st_sc1(myProg, (unsigned)W);
+    PHASE_STAMP(9);  // row tail
   }
+#ifdef DRYV_PHASE_PROFILE
+  if (lane0 == 0) {
+    const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    for (int i = 0; i < 10; i++) phaseOut[gw * 10 + i] = phaseAcc[i];
+  }
+#endif
 }
 
 size_t recon_lds_bytes(int wavesPerBlock) { return 1920 + (size_t)wavesPerBlock * sizeof(WaveScratch); }
@@ -757,7 +851,11 @@ size_t recon_lds_bytes(int wavesPerBlock) { return 1920 + (size_t)wavesPerBlock 
 size_t recon_workspace_bytes(int W, int H, int n_frames) {
   // [task counter | pad to 256] [row progress: n_frames*H u32 | pad to 256] [bottom-row modes: n_mbs u32]
   const size_t prog = (((size_t)n_frames * H * 4) + 255) & ~(size_t)255;
-  return 256 + prog + (size_t)n_frames * W * H * 4;
+  size_t bytes = 256 + prog + (size_t)n_frames * W * H * 4;
+#ifdef DRYV_PHASE_PROFILE
+  bytes = ((bytes + 255) & ~(size_t)255) + (size_t)65536 * 10 * 8;  // per-wave phase sums
+#endif
+  return bytes;
 }
 
 static size_t prog_bytes(const KParams& P) { return (((size_t)P.n_frames * P.H * 4) + 255) & ~(size_t)255; }
@@ -775,7 +873,11 @@ hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeff
   unsigned char* wsb = (unsigned char*)d_workspace;
   hipLaunchKernelGGL(recon_kernel, dim3(grid), dim3(wavesPerBlock * 64), ldsBytes, stream, P,
                      (const dryv_mb_desc*)d_mbs, (const int16_t*)d_coeffs, (uint8_t*)d_yuv, d_status,
-                     (unsigned*)(wsb + 256), (unsigned*)(wsb + 256 + prog_bytes(P)), (unsigned*)wsb);
+                     (unsigned*)(wsb + 256), (unsigned*)(wsb + 256 + prog_bytes(P)), (unsigned*)wsb
+#ifdef DRYV_PHASE_PROFILE
+                     , (unsigned long long*)(wsb + (((256 + prog_bytes(P) + (size_t)P.n_frames * P.W * P.H * 4) + 255) & ~(size_t)255))
+#endif
+                     );
   return hipGetLastError();
 }
 
