@@ -113,30 +113,42 @@ __device__ __forceinline__ unsigned quad_transpose_bytes(unsigned w, unsigned se
   return __builtin_amdgcn_perm(m, x, selB);
 }
 
+typedef __attribute__((address_space(3))) const int16_t* lds_i16p;
+typedef __attribute__((address_space(3))) const uint16_t* lds_u16p;
+typedef __attribute__((address_space(3))) const unsigned* lds_u32p;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4* lds_u4p;
+typedef __attribute__((address_space(3))) i32x4* lds_i4w;
+typedef __attribute__((address_space(3))) const int* lds_i32p;
+#define LDSP(T, a) ((T)(uintptr_t)(unsigned)(a))
+
 // ---- 4x4 residual, 4 lanes per block (transform.rs:116-191, 8.5.12) ---------------------------
-// In:  this lane is row `sq` of its block; list[k] = cs[listBase + k]; zz = 4 nibbles: list index of
-//      c[sq][0..3]. dcGiven: c[0][0] arrives already scaled (Intra16x16 / chroma, transform.rs:145-146).
+// In:  this lane is row sq of its block; a0..a3 = LDS byte addresses of c[sq][0..3] in the staged lists;
+//      lsAddr = LDS address of the four pre-shifted LevelScale words of (qp, row sq); qi = per-qp
+//      (rounding << 8 | right shift). dcLane: c[0][0] arrives already scaled (Intra16x16 / chroma,
+//      transform.rs:145-146) and this is the lane holding it.
+//      d = (c * (LS << max(qp/6-4, 0)) + rnd) >> max(4-qp/6, 0)  ==  transform.rs:147-152.
+// The 4x4 transpose between the row and the column butterfly goes through LDS (trW: this lane's 16 bytes,
+// trR: its column in the quad's 64 bytes): the SIMD is VALU-bound, the LDS pipe is not.
 // Out: r[k] = residual of the block at (x = sq, y = k) — the lane now owns COLUMN sq.
-__device__ __forceinline__ void residual4x4_quad(const int16_t* cs, int listBase, unsigned zz, bool dcGiven,
-                                                 int dcVal, int qp, const uint16_t* ls4, int sq, bool odd,
-                                                 bool hi, int r[4]) {
-  const int qd = (qp * 43) >> 8;  // qp / 6 for 0..51
-  const int qm = qp - 6 * qd;
-  const int shl = max(qd - 4, 0), shr = max(4 - qd, 0);
-  const int rnd = qd < 4 ? (1 << (3 - qd)) : 0;
-  const uint2 lsw = *(const uint2*)&ls4[qm * 16 + sq * 4];
-  const int ls[4] = {(int)(lsw.x & 0xffff), (int)(lsw.x >> 16), (int)(lsw.y & 0xffff), (int)(lsw.y >> 16)};
-  int d[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int c = cs[listBase + (int)((zz >> (4 * j)) & 15u)];
-    d[j] = ((c * ls[j]) * (1 << shl) + rnd) >> shr;
-  }
-  if (dcGiven && sq == 0) d[0] = dcVal;
+__device__ __forceinline__ void residual4x4_quad(int a0, int a1, int a2, int a3, bool dcLane, int dcVal, int lsAddr,
+                                                 unsigned qi, int trW, int trR, int r[4]) {
+  const int c0 = *LDSP(lds_i16p, a0), c1 = *LDSP(lds_i16p, a1), c2 = *LDSP(lds_i16p, a2), c3 = *LDSP(lds_i16p, a3);
+  const u32x4 ls = *LDSP(lds_u4p, lsAddr);
+  const int rnd = (int)(qi >> 8), shr = (int)(qi & 0xff);
+  int d0 = (__mul24(c0, (int)ls.x) + rnd) >> shr;
+  const int d1 = (__mul24(c1, (int)ls.y) + rnd) >> shr;
+  const int d2 = (__mul24(c2, (int)ls.z) + rnd) >> shr;
+  const int d3 = (__mul24(c3, (int)ls.w) + rnd) >> shr;
+  if (dcLane) d0 = dcVal;
   // row butterfly (transform.rs:159-169)
-  const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
-  int f0 = e0 + e3, f1 = e1 + e2, f2 = e1 - e2, f3 = e0 - e3;
-  quad_transpose4(f0, f1, f2, f3, odd, hi);  // lane sq now holds f[0..3][sq]
+  const int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
+  *LDSP(lds_i4w, trW) = i32x4{e0 + e3, e1 + e2, e1 - e2, e0 - e3};
+  WAVE_SYNC();
+  const int f0 = *LDSP(lds_i32p, trR), f1 = *LDSP(lds_i32p, trR + 16), f2 = *LDSP(lds_i32p, trR + 32),
+            f3 = *LDSP(lds_i32p, trR + 48);  // f[0..3][sq]
+  WAVE_SYNC();
   // column butterfly (transform.rs:171-181) and rounding (:183-187)
   const int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = f1 + (f3 >> 1);
   r[0] = (g0 + g3 + 32) >> 6;
@@ -171,18 +183,6 @@ __device__ __forceinline__ void idct8(const int d[8], int o[8]) {
   o[5] = f4 - f3;
   o[6] = f2 - f5;
   o[7] = f0 - f7;
-}
-
-// table 8-15 (transform.rs:194-216); qpy and offset are wave-uniform
-__device__ __forceinline__ int qpc_of(int qpy, int offset) {
-  const int qpi = min(max(qpy + offset, 0), 51);
-  if (qpi < 30) return qpi;
-  // qpi - QPCS[qpi - 30] for qpi = 30..51, 4 bits each
-  const unsigned long long dlo = 0x7765544332221111ull;  // qpi 30..45
-  const unsigned dhi = 0xCBA998u;                        // qpi 46..51
-  const int k = qpi - 30;
-  const int delta = k < 16 ? (int)((dlo >> (4 * k)) & 15ull) : (int)((dhi >> (4 * (k - 16))) & 15u);
-  return qpi - delta;
 }
 
 // Intra4x4 block schedule: step T runs the blocks with bx + 2*by == T (at most two: group 0 and 1)
@@ -363,6 +363,16 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
 #define UPC(pl, k) (36 + 16 * (pl) + (k))
 #define UPM 64
 
+// per-workgroup LDS tables
+#define LT_LSQ 0        // u32 [52][16]  LevelScale4x4(qp%6,i,j) << max(qp/6-4, 0)       (transform.rs:147-152)
+#define LT_QINFO 3328   // u16 [52]      rounding << 8 | right shift of the same formula
+#define LT_QPC 3440     // u8  [2][52]   QP'c for Cb / Cr as a function of QPY             (transform.rs:194-216)
+#define LT_LS8 3552     // u16 [6][64]   LevelScale8x8
+#define LT_T4X 4320     // u16 [10][16]  Intra4x4 gather table [mode][x][y]
+#define LT_T8 4640      // u8  [9][64]   Intra8x8 gather table
+#define LT_ZZ8 5216     // u8  [64]      raster -> 8x8 zig-zag list index
+#define LT_END 5280
+
 __global__ void __launch_bounds__(256, 8)
 recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_t* __restrict__ coeffs,
              uint8_t* __restrict__ yuv, unsigned* __restrict__ status, unsigned* __restrict__ rowProg,
@@ -377,15 +387,31 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   const int wave = rfl(threadIdx.x >> 6);
   const int W = P.W, H = P.H;
 
-  // ---- LDS carve ------------------------------------------------------------------------------
-  uint16_t* ls4 = (uint16_t*)(lds + 0);    // [6][16]
-  uint16_t* ls8 = (uint16_t*)(lds + 192);  // [6][64]
-  uint16_t* t4x = (uint16_t*)(lds + 960);  // [10][16]: (4*idx) | (8*sel) << 8; row 9 = zero prediction
-  uint8_t* t8 = lds + 1280;                // [9][64]
-  uint8_t* zz8i = lds + 1856;              // [64] raster -> list index
-  WaveScratch* ws = (WaveScratch*)(lds + 1920) + wave;
+  // ---- LDS tables (built once per workgroup) -------------------------------------------------------
+  unsigned* lsq = (unsigned*)(lds + LT_LSQ);
+  uint16_t* qinfo = (uint16_t*)(lds + LT_QINFO);
+  uint8_t* qpcT = lds + LT_QPC;
+  uint16_t* ls8 = (uint16_t*)(lds + LT_LS8);
+  uint16_t* t4x = (uint16_t*)(lds + LT_T4X);
+  uint8_t* t8 = lds + LT_T8;
+  uint8_t* zz8i = lds + LT_ZZ8;
+  WaveScratch* ws = (WaveScratch*)(lds + LT_END) + wave;
 
-  for (int i = threadIdx.x; i < 96; i += blockDim.x) ls4[i] = P.ls4[i];
+  for (int i = threadIdx.x; i < 52 * 16; i += blockDim.x) {
+    const int qp = i >> 4, qd = qp / 6, qm = qp - 6 * qd;
+    lsq[i] = (unsigned)P.ls4[qm * 16 + (i & 15)] << max(qd - 4, 0);
+  }
+  for (int i = threadIdx.x; i < 52; i += blockDim.x) {
+    const int qd = i / 6;
+    qinfo[i] = (uint16_t)((qd < 4 ? (1 << (3 - qd)) << 8 : 0) | max(4 - qd, 0));
+  }
+  for (int i = threadIdx.x; i < 104; i += blockDim.x) {
+    // 8.5.8: qPI = Clip3(0, 51, QPY + offset); QPc = qPI < 30 ? qPI : QPCS[qPI - 30] (table 8-15)
+    const int qpi = min(max((i % 52) + (i < 52 ? P.cqo_cb : P.cqo_cr), 0), 51);
+    const int k = qpi - 30;  // qPI - QPc for qPI = 30..51, 4 bits each
+    const int delta = k < 0 ? 0 : k < 16 ? (int)((0x7765544332221111ull >> (4 * k)) & 15ull) : (int)((0xCBA998u >> (4 * (k - 16))) & 15u);
+    qpcT[i] = (uint8_t)(qpi - delta);
+  }
   for (int i = threadIdx.x; i < 384; i += blockDim.x) ls8[i] = P.ls8[i];
   for (int i = threadIdx.x; i < 160; i += blockDim.x) {
     // t4x[mode][x][y]: low byte = 4 * lane index of the sample on the line (shifted by one, see I4Lane),
@@ -413,11 +439,20 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
 
+  // ---- per-lane values kept for the whole kernel ---------------------------------------------------
+  const int ldsBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const int wsAddr = (int)(uintptr_t)(__attribute__((address_space(3))) WaveScratch*)ws;
+  bool firstTask = true;
   for (;;) {
     // ---- claim the next macroblock row ---------------------------------------------------------
-    unsigned task = 0;
-    if (lane0 == 0) task = atomicAdd(taskCounter, 1u);
-    task = (unsigned)rfl((int)task);
+    // (the first one is this wave's global index: the queue counter starts at the number of waves)
+    unsigned tv = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (!firstTask) {
+      tv = 0;
+      if (lane0 == 0) tv = atomicAdd(taskCounter, 1u);
+    }
+    firstTask = false;
+    const unsigned task = (unsigned)rfl((int)tv);  // wave-uniform: everything derived from it stays scalar
     PHASE_STAMP(0);  // claim
     if (task >= totalTasks) break;
     const int r = (int)(task / (unsigned)P.n_frames);
@@ -432,9 +467,29 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
     const bool mbB = r > 0;
     unsigned upDone = 0;  // what we know of the row above's progress
 
+    // ---- per-row per-lane pointers, advanced by a constant stride per macroblock -----------------
+    // luma store: lane (block sb, row sq of the block) owns pixels x = 4*sbx..+3 of pixel row 16r + 4*sby + sq
+    // chroma store (lanes 0..31): plane cpl, pixel row 8r + 4*ccy + sq, x = 4*ccx..+3
+    // neighbour window: lanes 0..7 Y x = -4..27 of pixel row 16r-1; 8..11 Cb x = -4..11 of row 8r-1; 12..15 Cr; 16 modes
+    // (32-bit byte offsets from the frame's Y plane: a frame is < 4 GB; the modes live in their own buffer)
+    unsigned yOff, cOff, wOff;
+    {
+      int lr = lane0;
+      asm volatile("" : "+v"(lr));  // recompute per row rather than keep a dozen per-lane constants alive
+      const int sq = lr & 3, sb = lr >> 2;
+      const int sbx = ((sb >> 1) & 2) | (sb & 1), sby = ((sb >> 2) & 2) | ((sb >> 1) & 1);
+      const int cpl = (lr >> 4) & 1, ccb = (lr >> 2) & 3;
+      const unsigned offCb = (unsigned)W * H * 256u, offCr = offCb + (unsigned)W * H * 64u;
+      yOff = (unsigned)(r * 16 + 4 * sby + sq) * pitchY + 4 * sbx;
+      cOff = (cpl ? offCr : offCb) + (unsigned)(r * 8 + 4 * (ccb >> 1) + sq) * pitchC + 4 * (ccb & 1);
+      const unsigned wY = (unsigned)(r * 16 - 1) * pitchY - 4 + 4 * lr;
+      const unsigned wC = (lr < 12 ? offCb : offCr) + (unsigned)(r * 8 - 1) * pitchC - 4 + 4 * (lr & 3);
+      wOff = lr < 8 ? wY : wC;
+    }
+
     // coefficients of macroblock 0 of the row: global -> LDS DMA, 48 lanes x 16 B
-    const int16_t* crow = coeffs + mbBase * 384;
-    if (lane0 < 48) __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + lane0 * 8), (lds_void*)ws->coef, 16, 0, 0);
+    const uint8_t* crow = (const uint8_t*)(coeffs + mbBase * 384);
+    if (lane0 < 48) __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + lane0 * 16), (lds_void*)ws->coef, 16, 0, 0);
     uint4 desc = *(const uint4*)(mbs + mbBase);
 
     int Mprev = 2;  // derived modes of the macroblock to the left, on the 4x4 grid (lanes 0..15)
@@ -446,15 +501,18 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       asm volatile("" : "+v"(lane));
       // "strip" organisation: 4 lanes per 4x4 block, sb = blkIdx (z-order), sq = row (then column) in the block
       const int sq = lane & 3, sb = lane >> 2;
-      const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
       const int sbx = ((sb >> 1) & 2) | (sb & 1), sby = ((sb >> 2) & 2) | ((sb >> 1) & 1);
-      const unsigned zz = sq == 0 ? 0x6510u : sq == 1 ? 0xC742u : sq == 2 ? 0xDB83u : 0xFEA9u;
-      const unsigned selA = odd ? 0x03070105u : 0x06020400u, selB = hi ? 0x03020706u : 0x05040100u;
-      // chroma strips: lanes 0..31 = plane*16 + blk*4 + sq
+      const unsigned selA = (lane & 1) ? 0x03070105u : 0x06020400u, selB = (lane & 2) ? 0x03020706u : 0x05040100u;
+      // chroma strips: lanes 0..31 = plane*16 + blk*4 + sq (lanes 32..63 mirror them and are never stored)
       const int cpl = (lane >> 4) & 1, ccb = (lane >> 2) & 3, ccx = ccb & 1, ccy = ccb >> 1;
-      // mode grid: lanes 0..15 = by*4+bx (raster)
-      const int mbx = lane & 3, mby = (lane >> 2) & 3;
-      const int mzb = 8 * (mby >> 1) + 4 * (mbx >> 1) + 2 * (mby & 1) + (mbx & 1);
+      // LDS transpose slots of the residual passes (they live in the resTe area, free at that point)
+      const int trW = wsAddr + 768 + lane * 16, trR = wsAddr + 768 + (lane & ~3) * 16 + sq * 4;
+      // LDS byte addresses of the four coefficients c[sq][0..3] of an Intra4x4 luma block (list base 16*blk):
+      // inverse zig-zag (frame/mod.rs:185-209) as a per-lane gather. Other list layouts differ by a per-lane delta.
+      const unsigned zz = (unsigned)((0xFEA9DB83C7426510ull >> (16 * sq)) & 0xffffull);  // list indices of row sq
+      const int gaB = wsAddr + 32 * sb;
+      const int ga0 = gaB + 2 * (int)(zz & 15u), ga1 = gaB + 2 * (int)((zz >> 4) & 15u);
+      const int ga2 = gaB + 2 * (int)((zz >> 8) & 15u), ga3 = gaB + 2 * (int)(zz >> 12);
 
       const unsigned d0 = rfl(desc.x), d1 = rfl(desc.y), d2 = rfl(desc.z), d3 = rfl(desc.w);
       int kind = d0 & 0xff;
@@ -470,7 +528,6 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         qp = 0;
       }
       const bool mbA = mx > 0, mbC = mbB && (mx + 1 < W);
-      const int qpc0 = qpc_of(qp, P.cqo_cb), qpc1 = qpc_of(qp, P.cqo_cr);
 
       // Everything this wave issued so far has completed: the DMA of this macroblock's coefficients has
       // landed, and the pixel / mode stores of macroblock mx-1 have been written through -> publish it.
@@ -483,25 +540,24 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       const unsigned need = (unsigned)min(mx + 2, W);
       const bool winEarly = mbB && upDone >= need;
       unsigned pollv = 0, winv = 0;
-      // lanes 0..7: Y x = -4..27 of pixel row 16r-1; 8..11: Cb x = -4..11 of row 8r-1; 12..15: Cr; 16: modes
-      const unsigned* winSrc;
-      if (lane < 8) winSrc = (const unsigned*)(planeY + (size_t)(r * 16 - 1) * pitchY + mx * 16 - 4) + lane;
-      else if (lane < 12) winSrc = (const unsigned*)(planeCb + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 8);
-      else if (lane < 16) winSrc = (const unsigned*)(planeCr + (size_t)(r * 8 - 1) * pitchC + mx * 8 - 4) + (lane - 12);
-      else winSrc = myModes - W + mx;
       if (mbB) {
-        if (winEarly && lane < 17) winv = ld_sc1(winSrc);
+        if (winEarly) {
+          if (lane < 16) winv = ld_sc1((const unsigned*)(planeY + wOff));
+          else if (lane == 16) winv = ld_sc1(myModes - W + mx);
+        }
         if (lane == 0 && upDone < (unsigned)W) pollv = ld_sc1(upProg);
       }
       WAVE_SYNC();
 
       // ================= residuals (need no neighbour: done before waiting for the row above) =====
       int rl[4] = {0, 0, 0, 0};  // luma residual, column organisation (kinds 0 and 2)
-      int rc[4] = {0, 0, 0, 0};  // chroma residual (lanes 0..31)
+      int rc[4] = {0, 0, 0, 0};  // chroma residual
       if (kind != 3) {
-        // ---- chroma DC: 8.5.11 (trans_chroma.rs:369-415) on lanes plane*16 + blk*4 (+ sq) -----------
-        int dcC;
+        // ---- chroma: DC 2x2 (8.5.11, trans_chroma.rs:369-415) on lanes plane*16 + blk*4 (+ sq), then AC
         {
+          const int qc = (int)qpcT[cpl * 52 + qp];  // QP'c of this lane's plane
+          const unsigned qi = qinfo[qc];
+          const int lsA = ldsBase + LT_LSQ + qc * 64;
           int x = ws->coef[256 + cpl * 64 + ccb];
           // (both shifts execute on every lane: a DPP op under a divergent branch would see masked sources)
           int up = dpp<ROW_SHL(4)>(x, x), dn = dpp<ROW_SHR(4)>(x, x);
@@ -511,16 +567,16 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           dn = dpp<ROW_SHR(8)>(x, x);
           o = (ccb & 2) ? dn : up;  // lane ^ 8
           x = (ccb & 2) ? o - x : x + o;
-          const int qc = cpl ? qpc1 : qpc0;
-          const int qd = (qc * 43) >> 8, qm = qc - 6 * qd;
-          dcC = ((x * (int)ls4[qm * 16]) * (1 << qd)) >> 5;
+          // ((f * LS) << qp/6) >> 5 == (f * (LS << max(qp/6-4,0))) >> (max(4-qp/6,0) + 1)   (trans_chroma.rs:413)
+          const int dcC = (x * (int)*LDSP(lds_u32p, lsA)) >> ((int)(qi & 0xff) + 1);
+          // list of chroma block (plane, blk): DC slot + 15 AC at 256 + 64*plane + 4 + 15*blk - 1
+          const int dl = 2 * (259 + 64 * cpl + 15 * ccb) - 32 * sb;
+          residual4x4_quad(ga0 + dl, ga1 + dl, ga2 + dl, ga3 + dl, sq == 0, dcC, lsA + sq * 16, qi, trW, trR, rc);
         }
-        // ---- chroma AC + DC: lanes 0..31 ---------------------------------------------------------
-        if (lane < 32)
-          residual4x4_quad(ws->coef, 256 + cpl * 64 + 4 + ccb * 15 - 1, zz, true, dcC, cpl ? qpc1 : qpc0, ls4, sq, odd,
-                           hi, rc);
+        const unsigned qiY = qinfo[qp];
+        const int lsY = ldsBase + LT_LSQ + qp * 64;
         if (kind == 0) {
-          residual4x4_quad(ws->coef, sb * 16, zz, false, 0, qp, ls4, sq, odd, hi, rl);
+          residual4x4_quad(ga0, ga1, ga2, ga3, false, 0, lsY + sq * 16, qiY, trW, trR, rl);
         } else if (kind == 2) {
           // Intra16x16 luma DC: 8.5.10 (pred16x16.rs:428-482). The lanes of block (bx,by) load c[by][bx];
           // f = A c A = P (H c H) P^T with H the natural 4-point Hadamard and A row i = H row s(i),
@@ -538,10 +594,12 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           o = shfl(x, lane ^ 32);
           x = (sby & 2) ? o - x : x + o;
           const int fv = shfl(x, dcSrcLane);
-          const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
-          const int prod = fv * (int)ls4[qm * 16];
-          const int dcY = qp >= 36 ? prod * (1 << max(qd - 6, 0)) : ((prod + (1 << max(5 - qd, 0))) >> max(6 - qd, 0));
-          residual4x4_quad(ws->coef, 16 + sb * 15 - 1, zz, true, dcY, qp, ls4, sq, odd, hi, rl);
+          // qp >= 36: (f*LS) << (qp/6-6), else (f*LS + 2^(5-qp/6)) >> (6-qp/6)   (pred16x16.rs:465-479)
+          //   == (f * (LS << max(qp/6-4,0)) + max(4*rnd, 2)) >> (shr + 2) with (rnd, shr) of the 4x4 formula
+          const int dcY = (fv * (int)*LDSP(lds_u32p, lsY) + max(4 * (int)(qiY >> 8), 2)) >> ((int)(qiY & 0xff) + 2);
+          // list of luma block blk: DC slot + 15 AC at 16 + 15*blk - 1
+          const int dl = 30 - 2 * sb;
+          residual4x4_quad(ga0 + dl, ga1 + dl, ga2 + dl, ga3 + dl, sq == 0, dcY, lsY + sq * 16, qiY, trW, trR, rl);
         }
       }
 
@@ -568,14 +626,12 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           for (int k = 0; k < 8; k++) dd[k] = ws->g8[b8 * 64 + k * 8 + j];
           idct8(dd, oo);
         }
-        WAVE_SYNC();  // g8 aliases resB/tileY: everything is read before the residuals are written
+        WAVE_SYNC();  // g8 aliases resB: everything is read before the residuals are written
         if (lane < 32) {
           const int bx = b8 & 1, by = b8 >> 1;
 #pragma unroll
           for (int k = 0; k < 8; k++) ws->resB[(8 * by + k) * 16 + 8 * bx + i] = (int16_t)((oo[k] + 32) >> 6);
         }
-        // g8 also ran over the tile's left border: restore it from the contiguous copy
-        if (lane < 16) ws->tileY[TY(-1, lane)] = ws->leftY[lane];
       }
       WAVE_SYNC();
 
@@ -583,7 +639,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // the coefficient buffer is free again: start the DMA of the next macroblock and fetch its record
       if (mx + 1 < W) {
         if (lane < 48)
-          __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + (size_t)(mx + 1) * 384 + lane * 8),
+          __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + (size_t)(mx + 1) * 768 + lane * 16),
                                            (lds_void*)ws->coef, 16, 0, 0);
         desc = *(const uint4*)(mbs + mbBase + mx + 1);
       }
@@ -599,17 +655,21 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         }
         PHASE_STAMP(4);  // poll the row above
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: keep the loads below the poll
-        if (!winEarly && lane < 17) winv = ld_sc1(winSrc);
+        if (!winEarly) {
+          if (lane < 16) winv = ld_sc1((const unsigned*)(planeY + wOff));
+          else if (lane == 16) winv = ld_sc1(myModes - W + mx);
+        }
         if (lane < 17) ((unsigned*)ws->up)[lane] = winv;
         WAVE_SYNC();
       }
+      wOff += lane < 8 ? 16u : 8u;
       const uint8_t* up = ws->up;
       PHASE_STAMP(5);  // neighbour window fetch
 
-      // ================= chroma: 8.3.4 (trans_chroma.rs:96-366) on lanes 0..31 ====================
+      // ================= chroma: 8.3.4 (trans_chroma.rs:96-366) ===================================
       // lane = plane*16 + blk*4 + column sq; pixels (x = 4*ccx + sq, y = 4*ccy + k)
-      unsigned cword = 0;  // after the byte transpose: row sq of the block, 4 pixels
-      if (lane < 32) {
+      unsigned cword;  // after the byte transpose: row sq of the block, 4 pixels
+      {
         const uint8_t* upc = up + UPC(cpl, 0);
         const int x = 4 * ccx + sq;
         int pr[4] = {0, 0, 0, 0};
@@ -618,21 +678,16 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
             const unsigned tw = *(const unsigned*)&upc[4 * ccx];
             const unsigned lw = *(const unsigned*)&ws->leftC[cpl][4 * ccy];
             const int st = (int)sum4(tw), sl = (int)sum4(lw);
-            int v;
-            if (ccx == ccy) {  // blocks (0,0) and (4,4): trans_chroma.rs:174-226 incl. quirk Q2
-              if (mbB && mbA) v = (st + sl + 4) >> 3;
-              else if (!mbB && mbA) v = (sl + 2) >> 2;
-              else if (mbB && bytes_nonzero(tw)) v = (st + 2) >> 2;  // left missing: top needs all > 0
-              else v = 128;
-            } else if (ccx == 1) {  // block (4,0): :227-252
-              if (mbB) v = (st + 2) >> 2;
-              else if (mbA && (lw >> 24) != 0) v = (sl + 2) >> 2;
-              else v = 128;
-            } else {  // block (0,4): :253-278
-              if (mbA && (lw >> 24) != 0) v = (sl + 2) >> 2;
-              else if (mbB && (tw >> 24) != 0) v = (st + 2) >> 2;
-              else v = 128;
-            }
+            // trans_chroma.rs:168-286 incl. quirk Q2 (`> 0` where the spec means "available"), as selects:
+            //   blocks (0,0),(4,4): both -> 8-sample mean; left only -> left; top only needs every top sample > 0
+            //   block (4,0): top, else left if its 4th sample > 0;  block (0,4): left if its 4th sample > 0, else top if ...
+            const bool tAll = mbB && bytes_nonzero(tw);
+            const bool t3 = mbB && (tw >> 24) != 0, l3 = mbA && (lw >> 24) != 0;
+            const int vT = (st + 2) >> 2, vL = (sl + 2) >> 2, vB = (st + sl + 4) >> 3;
+            const int vDiag = (mbA && mbB) ? vB : mbA ? vL : tAll ? vT : 128;
+            const int vTR = mbB ? vT : l3 ? vL : 128;
+            const int vBL = l3 ? vL : t3 ? vT : 128;
+            const int v = ccx == ccy ? vDiag : ccx == 1 ? vTR : vBL;
             pr[0] = pr[1] = pr[2] = pr[3] = v;
           } else if (cmode == 1) {  // horizontal
             if (mbA) {
@@ -645,13 +700,12 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           } else if (mbA && mbB) {  // plane: :319-363
             // lanes (per plane) 0..3: horizontal terms, 4..7: vertical terms
             const int l16 = lane & 15, k = l16 & 3;
-            int term = 0;
-            if (l16 < 4) term = (k + 1) * ((int)upc[4 + k] - (int)upc[2 - k]);  // 2-k = -1 -> corner
-            else if (l16 < 8)
-              term = (k + 1) * ((int)ws->leftC[cpl][4 + k] - (k == 3 ? (int)upc[-1] : (int)ws->leftC[cpl][2 - k]));
+            const int ha = upc[4 + k], hb = upc[2 - k];  // 2-k = -1 -> corner
+            const int va = ws->leftC[cpl][4 + k], vb = k == 3 ? (int)upc[-1] : (int)ws->leftC[cpl][(2 - k) & 7];
+            int term = l16 < 4 ? (k + 1) * (ha - hb) : l16 < 8 ? (k + 1) * (va - vb) : 0;
             term += xor1(term);
             term += xor2(term);
-            const int hs = shfl(term, lane & 16), vs = shfl(term, (lane & 16) + 4);
+            const int hs = shfl(term, lane & 48), vs = shfl(term, (lane & 48) + 4);
             const int a = 16 * ((int)ws->leftC[cpl][7] + (int)upc[7]);
             const int b = (34 * hs + 32) >> 6, c = (34 * vs + 32) >> 6;
             const int base = a + b * (x - 3) + c * (4 * ccy - 3) + 16;
@@ -667,7 +721,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 
       PHASE_STAMP(6);  // chroma prediction
       // ================= luma ======================================================================
-      unsigned yword = 0;  // row strip of this lane's block, 4 pixels (kinds 2 and 3)
+      unsigned yword = 0;  // row strip of this lane's block, 4 pixels
       int Mcur = 2;        // derived modes on the 4x4 grid (lanes 0..15)
       if (kind == 2) {
         // Intra16x16: 8.3.3 (pred16x16.rs:79-425); lane = block sb, column sq: x = 4*sbx+sq, y = 4*sby+k
@@ -683,10 +737,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           }
         } else if (i16mode == 2) {
           // lanes 0..3: top words, 4..7: left words
-          unsigned wv = 0;
-          if (lane < 4) wv = *(const unsigned*)&up[UPY(4 * lane)];
-          else if (lane < 8) wv = *(const unsigned*)&ws->leftY[4 * (lane - 4)];
-          int s = (int)sum4(wv);
+          const unsigned wt = *(const unsigned*)&up[UPY(4 * (lane & 3))];
+          const unsigned wl = *(const unsigned*)&ws->leftY[4 * (lane & 3)];
+          int s = (int)sum4(lane < 4 ? wt : wl);
           s += xor1(s);
           s += xor2(s);
           const int st = __builtin_amdgcn_readlane(s, 0), sl = __builtin_amdgcn_readlane(s, 4);
@@ -699,10 +752,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         } else if (mbA && mbB) {
           // plane (:366-424): lanes 0..7 horizontal terms, 8..15 vertical terms
           const int k = lane & 7;
-          int term = 0;
-          if (lane < 8) term = (k + 1) * ((int)up[UPY(8 + k)] - (int)up[UPY(6 - k)]);  // 6-k = -1: corner
-          else if (lane < 16)
-            term = (k + 1) * ((int)ws->leftY[8 + k] - (k == 7 ? (int)up[UPY(-1)] : (int)ws->leftY[6 - k]));
+          const int ha = up[UPY(8 + k)], hb = up[UPY(6 - k)];  // 6-k = -1: corner
+          const int va = ws->leftY[8 + k], vb = k == 7 ? (int)up[UPY(-1)] : (int)ws->leftY[(6 - k) & 15];
+          int term = lane < 8 ? (k + 1) * (ha - hb) : lane < 16 ? (k + 1) * (va - vb) : 0;
           term += xor1(term);
           term += xor2(term);
           term += dpp<ROW_SHR(4)>(0, term);
@@ -718,6 +770,8 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         for (int k = 0; k < 4; k++) w |= (unsigned)clip255(pr[k] + rl[k]) << (8 * k);
         yword = quad_transpose_bytes(w, selA, selB);  // row sq of block sb: x = 4*sbx .. +3, y = 4*sby+sq
       } else if (kind == 0 || kind == 1) {
+        // mode grid: lanes 0..15 = by*4+bx (raster)
+        const int mbx = lane & 3, mby = (lane >> 2) & 3;
         // top border of the tile from the neighbour window; the left border is kept up to date
         if (lane < 25) ws->tileY[TY(lane - 1, -1)] = up[UPY(lane - 1)];
         const unsigned upM = mbB ? *(const unsigned*)&up[UPM] : 0x02020202u;
@@ -788,6 +842,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           }
           Mcur = M;
         }
+        yword = *(const unsigned*)&ws->tileY[TY(4 * sbx, 4 * sby + sq)];
       }
 
       PHASE_STAMP(7);  // luma prediction
@@ -795,33 +850,21 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // The bottom pixel line of the row (luma y = 15, chroma y = 7) and the bottom-row modes are what the
       // row below reads: they are stored write-through (sc1). Everything else is a plain write-back store.
       if (lane < 32) {  // chroma: row strip (plane cpl, row 4*ccy+sq, x = 4*ccx..+3)
-        const int cyy = 4 * ccy + sq;
-        uint8_t* pc = cpl ? planeCr : planeCb;
-        unsigned* dst = (unsigned*)(pc + (size_t)(r * 8 + cyy) * pitchC + mx * 8 + 4 * ccx);
-        if (cyy == 7) st_sc1(dst, cword);
-        else *dst = cword;
-        if (ccx == 1) ws->leftC[cpl][cyy] = (uint8_t)(cword >> 24);
+        if (ccy == 1 && sq == 3) st_sc1((unsigned*)(planeY + cOff), cword);
+        else *(unsigned*)(planeY + cOff) = cword;
+        if (ccx == 1) ws->leftC[cpl][4 * ccy + sq] = (uint8_t)(cword >> 24);
       }
+      cOff += 8;
       {
-        int y, xw;
-        unsigned w;
-        if (kind == 0 || kind == 1) {
-          y = lane >> 2;
-          xw = (lane & 3) * 4;
-          w = *(const unsigned*)&ws->tileY[TY(xw, y)];
-        } else {
-          y = 4 * sby + sq;
-          xw = 4 * sbx;
-          w = yword;
-        }
-        unsigned* dst = (unsigned*)(planeY + (size_t)(r * 16 + y) * pitchY + mx * 16 + xw);
-        if (y == 15) st_sc1(dst, w);
-        else *dst = w;
-        if (xw == 12) {
-          ws->leftY[y] = (uint8_t)(w >> 24);
-          ws->tileY[TY(-1, y)] = (uint8_t)(w >> 24);
+        const int y = 4 * sby + sq;
+        if (y == 15) st_sc1((unsigned*)(planeY + yOff), yword);
+        else *(unsigned*)(planeY + yOff) = yword;
+        if (sbx == 3) {
+          ws->leftY[y] = (uint8_t)(yword >> 24);
+          ws->tileY[TY(-1, y)] = (uint8_t)(yword >> 24);
         }
       }
+      yOff += 16;
       // bottom-row modes (grid lanes 12..15) for the row below; the whole grid for the macroblock to the right
       {
         const unsigned m4 = (unsigned)__builtin_amdgcn_readlane(Mcur, 12) | ((unsigned)__builtin_amdgcn_readlane(Mcur, 13) << 8) |
@@ -846,7 +889,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 #endif
 }
 
-size_t recon_lds_bytes(int wavesPerBlock) { return 1920 + (size_t)wavesPerBlock * sizeof(WaveScratch); }
+size_t recon_lds_bytes(int wavesPerBlock) { return LT_END + (size_t)wavesPerBlock * sizeof(WaveScratch); }
 
 size_t recon_workspace_bytes(int W, int H, int n_frames) {
   // [task counter | pad to 256] [row progress: n_frames*H u32 | pad to 256] [bottom-row modes: n_mbs u32]
@@ -862,8 +905,11 @@ static size_t prog_bytes(const KParams& P) { return (((size_t)P.n_frames * P.H *
 
 // the task counter and the row-progress words start every launch at zero (the modes need no reset:
 // every word is written before it is read)
-hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, hipStream_t stream) {
-  return hipMemsetAsync(d_workspace, 0, 256 + prog_bytes(P), stream);
+hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, int grid, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_workspace, 0, 256 + prog_bytes(P), stream);
+  if (e != hipSuccess) return e;
+  // every wave starts on the task equal to its global index; the queue hands out the rest
+  return hipMemsetD32Async((hipDeviceptr_t)d_workspace, grid * 4, 1, stream);
 }
 
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,

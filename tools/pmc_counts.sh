@@ -3,7 +3,7 @@
 # usage: tools/pmc_counts.sh <outdir>
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=${1:-$R/gpurun_out/pmc}
+OUT=$(realpath -m ${1:-$R/gpurun_out/pmc})
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES \
