@@ -168,11 +168,11 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   if (st != DRYV_OK) return st;
   hipError_t e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
-  // Persistent grid: 4-wave workgroups, enough to hold 32 waves on every CU; each wave keeps claiming
-  // macroblock rows until none are left, so a smaller grid is merely slower and never incorrect.
-  const long long total_rows = (long long)P.n_frames * P.H;
+  // Persistent grid: 4-wave workgroups, 8 per CU; each workgroup keeps claiming 4-row bands until none are left,
+  // so a smaller grid is merely slower and never incorrect.
+  const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * 8;
-  if (grid > (total_rows + 3) / 4) grid = (total_rows + 3) / 4;
+  if (grid > total_bands) grid = total_bands;
   if (grid < 1) grid = 1;
   e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");

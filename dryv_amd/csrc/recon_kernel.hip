@@ -1,22 +1,24 @@
 // recon_kernel.hip — gfx950 (CDNA4 / MI355X) macroblock reconstruction for dryv's AVC intra path.
 //
 // Work decomposition
-//   * The unit of work is one macroblock ROW of one frame, processed left to right by one 64-lane
-//     wavefront. Rows are claimed from a global queue in the order (row 0 of every frame, row 1 of every
-//     frame, ...): the row a task depends on was always claimed earlier, so its owner is running or done
-//     and a waiting wave can never deadlock, whatever the residency. Any wave on any CU can take any row:
-//     300 independent frames spread evenly over 256 CUs x 32 waves.
-//   * Rows of a frame advance as a 2:1 diagonal: row r may process macroblock x once row r-1 has
-//     published macroblock x+1 (top-right neighbour C; reference slice/macroblock.rs:455-456,
-//     slice/mod.rs:593-598). Hand-off between rows goes through L2 (MI355X_MICROARCH.md, "valid forms"):
-//     the producer stores each row's BOTTOM pixel line and bottom-row prediction modes write-through
-//     (sc1, relaxed agent-scope stores), waits for vmcnt(0), then stores its progress counter (sc1);
-//     the consumer polls that counter with sc1 loads and then reads the 25+9+9 neighbour samples and the
-//     modes with sc1 loads only (they bypass the CU's L1, so no acquire/invalidate is needed). All other
-//     pixel rows are plain write-back stores that L2 merges into full lines.
+//   * One 64-lane wavefront processes one macroblock ROW of one frame, left to right. Rows of a frame advance
+//     as a 2:1 diagonal: row r may process macroblock x once row r-1 has finished macroblock x+1 (top-right
+//     neighbour C; reference slice/macroblock.rs:455-456, slice/mod.rs:593-598).
+//   * The unit handed out by the global queue is a BAND: 4 consecutive rows of one frame, one per wave of a
+//     256-thread workgroup. Inside a band, rows hand off through a 16-macroblock LDS ring (bottom pixel line +
+//     bottom-row prediction modes) with two-way LDS progress counters: a hand-off costs ~100 cycles, so the four
+//     rows run at the minimum legal lag of 2 macroblocks.
+//   * Between bands the hand-off goes through L2 (MI355X_MICROARCH.md, "valid forms"): the last row of a band
+//     stores its bottom pixel line and modes write-through (sc1), drains vmcnt, then stores its progress counter
+//     (sc1); wave 0 of the band below polls that counter and reads the 25+9+9 neighbour samples with sc1 loads
+//     only (they bypass the CU's L1, so no acquire/invalidate is needed). Bands are claimed in the order (band 0
+//     of every frame, band 1 of every frame, ...): the band a task depends on was always claimed earlier, so its
+//     owner is running or done and a waiting wave can never deadlock; and it is ~4 x (frames x W / waves)
+//     macroblocks ahead, so this slow hand-off practically never blocks. Any workgroup can take any band:
+//     300 independent frames spread evenly over 256 CUs.
 //   * HBM traffic per macroblock: 768 B of coefficients in (one global->LDS DMA of 48 x 16 B, issued a
-//     macroblock ahead), a 16 B record, 384 B of pixels out (one dword per lane) + 4 B of modes, and a
-//     68 B neighbour window re-read through L2.
+//     macroblock ahead), a 16 B record, 384 B of pixels out (one dword per lane); per band boundary row 4 B of
+//     modes and a 68 B neighbour window re-read through L2.
 //
 // Inside a macroblock (registers / DPP unless noted)
 //   * residual: 4 lanes per 4x4 block; lane = one row of coefficients (inverse zig-zag is a 4-way LDS
@@ -359,6 +361,17 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
 #define PHASE_STAMP(i) do { } while (0)
 #endif
 
+#define BAND 4     // rows per band = waves per workgroup
+#define RING_K 16  // macroblocks of bottom line each row keeps in LDS for the row below (power of two)
+struct BandShared {
+  unsigned prog[BAND];  // prog[w]: macroblocks of wave w's row finished and present in its ring
+  unsigned cons[BAND];  // cons[w]: macroblocks whose neighbour window wave w has copied out of wave w-1's ring
+  unsigned task, pad[3];
+  uint8_t ringY[BAND][RING_K * 16];     // bottom luma line, macroblock e at (e % RING_K) * 16
+  uint8_t ringC[BAND][2][RING_K * 8];   // bottom chroma lines
+  unsigned ringM[BAND][RING_K];         // bottom-row prediction modes
+};
+
 #define UPY(k) (4 + (k))        // byte index in WaveScratch::up of luma sample x = k of the row above
 #define UPC(pl, k) (36 + 16 * (pl) + (k))
 #define UPM 64
@@ -396,6 +409,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   uint8_t* t8 = lds + LT_T8;
   uint8_t* zz8i = lds + LT_ZZ8;
   WaveScratch* ws = (WaveScratch*)(lds + LT_END) + wave;
+  BandShared* bs = (BandShared*)(lds + LT_END + BAND * sizeof(WaveScratch));
 
   for (int i = threadIdx.x; i < 52 * 16; i += blockDim.x) {
     const int qp = i >> 4, qd = qp / 6, qm = qp - 6 * qd;
@@ -432,7 +446,6 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 
   const size_t frameBytes = (size_t)W * H * 384;
   const int pitchY = W * 16, pitchC = W * 8;
-  const unsigned totalTasks = (unsigned)P.n_frames * (unsigned)H;
 #ifdef DRYV_PHASE_PROFILE
   unsigned long long phaseAcc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long phaseT = __builtin_amdgcn_s_memtime();
@@ -442,21 +455,27 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   // ---- per-lane values kept for the whole kernel ---------------------------------------------------
   const int ldsBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   const int wsAddr = (int)(uintptr_t)(__attribute__((address_space(3))) WaveScratch*)ws;
+  const unsigned bandsPerFrame = (unsigned)(H + BAND - 1) / BAND;
+  const unsigned totalBands = (unsigned)P.n_frames * bandsPerFrame;
   bool firstTask = true;
   for (;;) {
-    // ---- claim the next macroblock row ---------------------------------------------------------
-    // (the first one is this wave's global index: the queue counter starts at the number of waves)
-    unsigned tv = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (!firstTask) {
-      tv = 0;
-      if (lane0 == 0) tv = atomicAdd(taskCounter, 1u);
-    }
+    // ---- claim the next band (the first one is this workgroup's index: the queue counter starts at gridDim) --
+    if (threadIdx.x == 0) bs->task = firstTask ? blockIdx.x : atomicAdd(taskCounter, 1u);
+    if (threadIdx.x < 2 * BAND) bs->prog[threadIdx.x] = 0;  // prog[] and cons[] are adjacent
     firstTask = false;
-    const unsigned task = (unsigned)rfl((int)tv);  // wave-uniform: everything derived from it stays scalar
+    __syncthreads();
+    const unsigned task = (unsigned)rfl((int)bs->task);  // wave-uniform: everything derived from it stays scalar
     PHASE_STAMP(0);  // claim
-    if (task >= totalTasks) break;
-    const int r = (int)(task / (unsigned)P.n_frames);
-    const int f = (int)(task - (unsigned)r * (unsigned)P.n_frames);
+    if (task >= totalBands) break;
+    const int bandRow = (int)(task / (unsigned)P.n_frames);
+    const int f = (int)(task - (unsigned)bandRow * (unsigned)P.n_frames);
+    const int r = bandRow * BAND + wave;
+    if (r < H) {
+    // where the row above comes from, and who reads this row's bottom line
+    const bool upLds = wave > 0;                       // row r-1 is wave-1 of this band: LDS ring
+    const bool upGlobal = wave == 0 && r > 0;          // row r-1 is the last row of the band above: through L2
+    const bool toLds = wave + 1 < BAND && r + 1 < H;   // row r+1 is the next wave of this band
+    const bool toGlobal = wave + 1 == BAND && r + 1 < H;
     const size_t mbBase = (size_t)f * W * H + (size_t)r * W;
     uint8_t* planeY = yuv + (size_t)f * frameBytes;
     uint8_t* planeCb = planeY + (size_t)W * H * 256;
@@ -534,13 +553,13 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       PHASE_STAMP(1);  // record decode, constants
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PHASE_STAMP(2);  // wait for DMA + previous stores
-      if (mx > 0 && lane == 0) st_sc1(myProg, (unsigned)mx);
+      if (toGlobal && mx > 0 && lane == 0) st_sc1(myProg, (unsigned)mx);
       // Row above: start its progress poll now, and -- when what we already know of its progress covers this
       // macroblock -- the loads of the neighbour window too; both L2 round trips then hide under the residuals.
       const unsigned need = (unsigned)min(mx + 2, W);
-      const bool winEarly = mbB && upDone >= need;
+      const bool winEarly = upGlobal && upDone >= need;
       unsigned pollv = 0, winv = 0;
-      if (mbB) {
+      if (upGlobal) {
         if (winEarly) {
           if (lane < 16) winv = ld_sc1((const unsigned*)(planeY + wOff));
           else if (lane == 16) winv = ld_sc1(myModes - W + mx);
@@ -645,7 +664,23 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
 
       // ================= wait for the row above, fetch the neighbour window ======================
-      if (mbB) {
+      if (upLds) {
+        // row above = wave-1 of this band: poll its LDS counter, copy the window out of its ring, tell it so
+        while (__hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+          __builtin_amdgcn_s_sleep(1);
+        PHASE_STAMP(4);  // poll the row above
+        if (lane < 17) {
+          // dword j of the window: Y (lanes 0..7) covers x = 4j-4..4j-1, Cb/Cr (lanes 8..11 / 12..15) likewise with 8-pixel macroblocks
+          const int jy = lane, jc = lane & 3;
+          const int ey = mx + ((jy + 3) >> 2) - 1, ec = mx + ((jc + 1) >> 1) - 1;
+          const uint8_t* src = lane < 8    ? &bs->ringY[wave - 1][(ey & (RING_K - 1)) * 16 + ((jy + 3) & 3) * 4]
+                               : lane < 16 ? &bs->ringC[wave - 1][(lane >> 2) & 1][(ec & (RING_K - 1)) * 8 + ((jc + 1) & 1) * 4]
+                                           : (const uint8_t*)&bs->ringM[wave - 1][mx & (RING_K - 1)];
+          ((unsigned*)ws->up)[lane] = *(const unsigned*)src;
+        }
+        WAVE_SYNC();
+        if (lane == 0) __hip_atomic_store(&bs->cons[wave], (unsigned)(mx + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (upGlobal) {
         upDone = max(upDone, (unsigned)rfl((int)pollv));
         while (upDone < need) {
           unsigned v = 0;
@@ -847,18 +882,32 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 
       PHASE_STAMP(7);  // luma prediction
       // ================= write-out ==================================================================
-      // The bottom pixel line of the row (luma y = 15, chroma y = 7) and the bottom-row modes are what the
-      // row below reads: they are stored write-through (sc1). Everything else is a plain write-back store.
+      // The bottom pixel line of the row (luma y = 15, chroma y = 7) and the bottom-row modes are what the row
+      // below reads. Inside a band they go to this wave's LDS ring; on a band's last row they are stored
+      // write-through (sc1) for the band below. Everything else is a plain write-back store.
+      const unsigned m4 = (unsigned)__builtin_amdgcn_readlane(Mcur, 12) | ((unsigned)__builtin_amdgcn_readlane(Mcur, 13) << 8) |
+                          ((unsigned)__builtin_amdgcn_readlane(Mcur, 14) << 16) |
+                          ((unsigned)__builtin_amdgcn_readlane(Mcur, 15) << 24);
+      const int slotK = mx & (RING_K - 1);
+      if (toLds) {
+        // ring entry mx replaces entry mx-RING_K, which the row below needs until it has copied the window of
+        // macroblock mx-RING_K+1
+        while ((int)__hip_atomic_load(&bs->cons[wave + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < mx - RING_K + 2)
+          __builtin_amdgcn_s_sleep(1);
+      }
       if (lane < 32) {  // chroma: row strip (plane cpl, row 4*ccy+sq, x = 4*ccx..+3)
-        if (ccy == 1 && sq == 3) st_sc1((unsigned*)(planeY + cOff), cword);
+        const bool bottom = ccy == 1 && sq == 3;
+        if (bottom && toGlobal) st_sc1((unsigned*)(planeY + cOff), cword);
         else *(unsigned*)(planeY + cOff) = cword;
+        if (bottom && toLds) *(unsigned*)&bs->ringC[wave][cpl][slotK * 8 + 4 * ccx] = cword;
         if (ccx == 1) ws->leftC[cpl][4 * ccy + sq] = (uint8_t)(cword >> 24);
       }
       cOff += 8;
       {
         const int y = 4 * sby + sq;
-        if (y == 15) st_sc1((unsigned*)(planeY + yOff), yword);
+        if (y == 15 && toGlobal) st_sc1((unsigned*)(planeY + yOff), yword);
         else *(unsigned*)(planeY + yOff) = yword;
+        if (y == 15 && toLds) *(unsigned*)&bs->ringY[wave][slotK * 16 + 4 * sbx] = yword;
         if (sbx == 3) {
           ws->leftY[y] = (uint8_t)(yword >> 24);
           ws->tileY[TY(-1, y)] = (uint8_t)(yword >> 24);
@@ -866,20 +915,24 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
       yOff += 16;
       // bottom-row modes (grid lanes 12..15) for the row below; the whole grid for the macroblock to the right
-      {
-        const unsigned m4 = (unsigned)__builtin_amdgcn_readlane(Mcur, 12) | ((unsigned)__builtin_amdgcn_readlane(Mcur, 13) << 8) |
-                            ((unsigned)__builtin_amdgcn_readlane(Mcur, 14) << 16) |
-                            ((unsigned)__builtin_amdgcn_readlane(Mcur, 15) << 24);
-        if (lane == 0) st_sc1(myModes + mx, m4);
+      if (toGlobal && lane == 0) st_sc1(myModes + mx, m4);
+      if (toLds) {
+        if (lane == 0) bs->ringM[wave][slotK] = m4;
+        WAVE_SYNC();
+        if (lane == 0) __hip_atomic_store(&bs->prog[wave], (unsigned)(mx + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       Mprev = Mcur;
       WAVE_SYNC();
       PHASE_STAMP(8);  // write-out
     }
     // the row is complete once its last stores have been written through
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane0 == 0) st_sc1(myProg, (unsigned)W);
+    if (toGlobal) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane0 == 0) st_sc1(myProg, (unsigned)W);
+    }
     PHASE_STAMP(9);  // row tail
+    }  // r < H
+    __syncthreads();  // the band is done: its ring and counters may be reused
   }
 #ifdef DRYV_PHASE_PROFILE
   if (lane0 == 0) {
@@ -889,7 +942,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 #endif
 }
 
-size_t recon_lds_bytes(int wavesPerBlock) { return LT_END + (size_t)wavesPerBlock * sizeof(WaveScratch); }
+size_t recon_lds_bytes(int wavesPerBlock) { return LT_END + (size_t)wavesPerBlock * sizeof(WaveScratch) + sizeof(BandShared); }
 
 size_t recon_workspace_bytes(int W, int H, int n_frames) {
   // [task counter | pad to 256] [row progress: n_frames*H u32 | pad to 256] [bottom-row modes: n_mbs u32]
@@ -908,8 +961,8 @@ static size_t prog_bytes(const KParams& P) { return (((size_t)P.n_frames * P.H *
 hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, int grid, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_workspace, 0, 256 + prog_bytes(P), stream);
   if (e != hipSuccess) return e;
-  // every wave starts on the task equal to its global index; the queue hands out the rest
-  return hipMemsetD32Async((hipDeviceptr_t)d_workspace, grid * 4, 1, stream);
+  // every workgroup starts on the band equal to its index; the queue hands out the rest
+  return hipMemsetD32Async((hipDeviceptr_t)d_workspace, grid, 1, stream);
 }
 
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
