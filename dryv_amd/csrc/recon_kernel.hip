@@ -361,6 +361,25 @@ __device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
 #define PHASE_STAMP(i) do { } while (0)
 #endif
 
+// Coefficient prefetch: global -> LDS DMA issued from inline asm (cdna_hip_programming.md §5.7). hipcc treats an
+// LDS-DMA it knows about as a pending write to ALL of LDS and waits vmcnt(0) at the next LDS access, which turns
+// the prefetch into a synchronous load. Hidden from the compiler it is retired by the counted s_waitcnt at the top
+// of the macroblock loop. (vmcnt is in-order: a hidden operation can only make the compiler's own counted waits
+// stricter, never looser. Buffer form: scalar resource + scalar offset + one per-lane VGPR offset.)
+__device__ __forceinline__ void dma_coefficients(int ldsAddr, unsigned voff, i32x4 rsrc, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(ldsAddr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
+// one dword per active lane from a per-lane global address, write-through-coherent (sc1), to LDS ldsAddr + 4*lane;
+// hidden from the compiler for the same reason (and because a conditionally issued VGPR load leaves its
+// destination "possibly pending" in hipcc's scoreboard, which then waits vmcnt(0) before reusing that register)
+__device__ __forceinline__ void dma_window(int ldsAddr, const unsigned* src) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1" : : "s"(ldsAddr), "v"(src) : "memory");
+}
+
 #define BAND 4     // rows per band = waves per workgroup
 #define RING_K 16  // macroblocks of bottom line each row keeps in LDS for the row below (power of two)
 struct BandShared {
@@ -508,7 +527,10 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 
     // coefficients of macroblock 0 of the row: global -> LDS DMA, 48 lanes x 16 B
     const uint8_t* crow = (const uint8_t*)(coeffs + mbBase * 384);
-    if (lane0 < 48) __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + lane0 * 16), (lds_void*)ws->coef, 16, 0, 0);
+    // buffer resource over this row's coefficients (raw buffer, 32-bit data format: dword 3 = 0x00020000 on gfx9)
+    const unsigned long long crowBits = (unsigned long long)(uintptr_t)crow;
+    const i32x4 crsrc = {(int)(unsigned)crowBits, (int)(unsigned)((crowBits >> 32) & 0xffffull), W * 768, 0x00020000};
+    if (lane0 < 48) dma_coefficients(wsAddr, (unsigned)lane0 * 16u, crsrc, 0);  // WaveScratch::coef is the first member
     uint4 desc = *(const uint4*)(mbs + mbBase);
 
     int Mprev = 2;  // derived modes of the macroblock to the left, on the 4x4 grid (lanes 0..15)
@@ -548,23 +570,30 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
       const bool mbA = mx > 0, mbC = mbB && (mx + 1 < W);
 
-      // Everything this wave issued so far has completed: the DMA of this macroblock's coefficients has
-      // landed, and the pixel / mode stores of macroblock mx-1 have been written through -> publish it.
+      // The DMA of this macroblock's coefficients must have landed. vmcnt is ONE in-order counter for loads,
+      // stores and LDS-DMA, so the wait is counted: after the DMA a wave inside a band issues exactly its two
+      // plain pixel stores, and "all but the 2 youngest operations done" covers the DMA without waiting for them.
+      // A band's LAST row drains completely instead: its write-through stores of macroblock mx-1 must have
+      // retired before that macroblock is published to the band below, and publishing early keeps the ramp of
+      // the 27-row wavefront at launch short. (Macroblock 0 of a row: nothing was issued after its DMA.)
       PHASE_STAMP(1);  // record decode, constants
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PHASE_STAMP(2);  // wait for DMA + previous stores
+      // (the builtin, not inline asm: hipcc's wait-count pass then accounts for it)
+      if (mx == 0 || toGlobal) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(0x0F72);                      // vmcnt(2)
+      asm volatile("" ::: "memory");
+      PHASE_STAMP(2);  // wait for the coefficient DMA
       if (toGlobal && mx > 0 && lane == 0) st_sc1(myProg, (unsigned)mx);
-      // Row above: start its progress poll now, and -- when what we already know of its progress covers this
-      // macroblock -- the loads of the neighbour window too; both L2 round trips then hide under the residuals.
+      // Band boundary (wave 0 only): the row above lives in another workgroup. Start the poll of its progress
+      // now and -- when what we already know of its progress covers this macroblock -- the loads of the neighbour
+      // window too; both L2 round trips then hide under the residuals. Lanes 0..15 pixels, lane 16 the modes word
+      // (window), lane 17 the progress word; all land in WaveScratch::up.
       const unsigned need = (unsigned)min(mx + 2, W);
       const bool winEarly = upGlobal && upDone >= need;
-      unsigned pollv = 0, winv = 0;
+      const bool pollEarly = upGlobal && upDone < (unsigned)W;
       if (upGlobal) {
-        if (winEarly) {
-          if (lane < 16) winv = ld_sc1((const unsigned*)(planeY + wOff));
-          else if (lane == 16) winv = ld_sc1(myModes - W + mx);
-        }
-        if (lane == 0 && upDone < (unsigned)W) pollv = ld_sc1(upProg);
+        const unsigned* src = lane < 16 ? (const unsigned*)(planeY + wOff) : lane == 16 ? myModes - W + mx : upProg;
+        const bool act = lane < 17 ? winEarly : (lane == 17 && pollEarly);
+        if (act) dma_window(wsAddr + (int)offsetof(WaveScratch, up), src);
       }
       WAVE_SYNC();
 
@@ -655,13 +684,18 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       WAVE_SYNC();
 
       PHASE_STAMP(3);  // residuals
+      // the early poll / window loads are drained BEFORE the next coefficient DMA is issued
+      if (upGlobal) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's hidden window / poll loads have landed
+        if (pollEarly) upDone = max(upDone, (unsigned)rfl((int)((const unsigned*)ws->up)[17]));
+      }
+      asm volatile("" ::: "memory");
       // the coefficient buffer is free again: start the DMA of the next macroblock and fetch its record
       if (mx + 1 < W) {
-        if (lane < 48)
-          __builtin_amdgcn_global_load_lds((global_cvoid*)(crow + (size_t)(mx + 1) * 768 + lane * 16),
-                                           (lds_void*)ws->coef, 16, 0, 0);
+        if (lane < 48) dma_coefficients(wsAddr, (unsigned)lane * 16u, crsrc, (mx + 1) * 768);  // (opaque lane: not hoisted/spilled)
         desc = *(const uint4*)(mbs + mbBase + mx + 1);
       }
+      asm volatile("" ::: "memory");
 
       // ================= wait for the row above, fetch the neighbour window ======================
       if (upLds) {
@@ -680,8 +714,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         }
         WAVE_SYNC();
         if (lane == 0) __hip_atomic_store(&bs->cons[wave], (unsigned)(mx + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (upGlobal) {
-        upDone = max(upDone, (unsigned)rfl((int)pollv));
+      } else if (upGlobal && !winEarly) {
         while (upDone < need) {
           unsigned v = 0;
           if (lane == 0) v = ld_sc1(upProg);
@@ -690,13 +723,12 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         }
         PHASE_STAMP(4);  // poll the row above
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: keep the loads below the poll
-        if (!winEarly) {
-          if (lane < 16) winv = ld_sc1((const unsigned*)(planeY + wOff));
-          else if (lane == 16) winv = ld_sc1(myModes - W + mx);
+        if (lane < 17) {
+          const unsigned* src = lane < 16 ? (const unsigned*)(planeY + wOff) : myModes - W + mx;
+          ((unsigned*)ws->up)[lane] = ld_sc1(src);
         }
-        if (lane < 17) ((unsigned*)ws->up)[lane] = winv;
-        WAVE_SYNC();
       }
+      WAVE_SYNC();
       wOff += lane < 8 ? 16u : 8u;
       const uint8_t* up = ws->up;
       PHASE_STAMP(5);  // neighbour window fetch

@@ -50,6 +50,12 @@ def main():
     for name, v in zip(PHASES, tot):
         print("  %-18s %6.2f %%   %8.0f cycles/MB" % (name, 100 * v / tot.sum(), v / mbs.size))
     print("  total %.0f wave-cycles/MB" % (tot.sum() / mbs.size))
+    # by position of the wave in its 4-row band (wave 0 reads the band above through L2, 1..3 through the LDS ring)
+    for w in range(4):
+        sub = out[w::4].sum(axis=0).astype(np.float64)
+        share = 100 * sub / sub.sum()
+        print("  band wave %d: " % w + "  ".join("%s %.1f%%" % (n.split()[0], v) for n, v in zip(PHASES, share) if v >= 1.0)
+              + "   | cycles/MB of this wave: %.0f" % (sub.sum() / (mbs.size / 4)))
     lib.dryv_recon_destroy(h)
 
 
