@@ -51,8 +51,22 @@ def build_synth(force=False):
     return SYNTH_SO
 
 
+HARNESS = os.path.join(LIB, "frame_harness")
+
+
+def build_harness(force=False):
+    """C++ host mirror of the reference's Frame interface (host/frame.hpp) + its harness binary."""
+    host = os.path.join(HERE, "host")
+    srcs = [os.path.join(host, "frame_harness.cpp"), os.path.join(host, "frame.hpp")]
+    build_recon(force)
+    if force or _stale(HARNESS, srcs + [RECON_SO]):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-o", HARNESS, srcs[0], "-L" + LIB, "-ldryv_recon",
+              "-Wl,-rpath," + LIB, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    return HARNESS
+
+
 def build_all(force=False):
-    return [build_recon(force), build_synth(force)]
+    return [build_recon(force), build_synth(force), build_harness(force)]
 
 
 if __name__ == "__main__":

@@ -1,0 +1,77 @@
+// frame_harness.cpp — exercises dryv::Frame (host/frame.hpp) the way dryv's decoder would: one
+// Frame per picture, Frame::decode per macroblock in mbaddr order, write_to_yuv_file at the end.
+//
+//   frame_harness <in.batch> <out.yuv>
+// in.batch: dryv_frame_params (496 B) | u32 n_frames | dryv_mb_desc[n] | int16 coeffs[n][384]
+// (written by tests/test_host_harness.py from the synthetic generator). Frames are written back to back.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "frame.hpp"
+
+static dryv::Macroblock unpack(const dryv_mb_desc& d, const int16_t* c) {
+  dryv::Macroblock mb;
+  mb.mode = d.mb_kind;
+  mb.intra16x16_pred_mode = d.i16_pred_mode;
+  mb.intra_chroma_pred_mode = d.intra_chroma_pred_mode;
+  mb.qpy = d.qp;
+  for (int i = 0; i < 16; i++) {
+    const int prev = (d.prev_flags >> i) & 1, rem = (d.rem_modes[i >> 1] >> (4 * (i & 1))) & 7;
+    mb.prev_intra4x4_pred_mode_flag[i] = (uint8_t)prev;
+    mb.rem_intra4x4_pred_mode[i] = (uint8_t)rem;
+    if (i < 4) {
+      mb.prev_intra8x8_pred_mode_flag[i] = (uint8_t)prev;
+      mb.rem_intra8x8_pred_mode[i] = (uint8_t)rem;
+    }
+  }
+  if (d.mb_kind == 0) {
+    for (int b = 0; b < 16; b++) for (int k = 0; k < 16; k++) mb.block_luma_4x4[b][k] = *c++;
+  } else if (d.mb_kind == 1) {
+    for (int b = 0; b < 4; b++) for (int k = 0; k < 64; k++) mb.block_luma_8x8[b][k] = *c++;
+  } else {
+    for (int k = 0; k < 16; k++) mb.block_luma_dc[k] = *c++;
+    for (int b = 0; b < 16; b++) for (int k = 0; k < 15; k++) mb.block_luma_ac[b][k] = *c++;
+  }
+  for (int pl = 0; pl < 2; pl++) {
+    for (int k = 0; k < 4; k++) mb.block_chroma_dc[pl][k] = *c++;
+    for (int b = 0; b < 4; b++) for (int k = 0; k < 15; k++) mb.block_chroma_ac[pl][b][k] = *c++;
+  }
+  return mb;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 3) { std::fprintf(stderr, "usage: %s in.batch out.yuv\n", argv[0]); return 2; }
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) { std::perror("open"); return 2; }
+  dryv_frame_params fp;
+  uint32_t n_frames = 0;
+  if (std::fread(&fp, sizeof(fp), 1, f) != 1 || std::fread(&n_frames, 4, 1, f) != 1) return 2;
+  const size_t per = (size_t)fp.pic_width_in_mbs * fp.pic_height_in_mbs, n = per * n_frames;
+  std::vector<dryv_mb_desc> mbs(n);
+  std::vector<int16_t> co(n * DRYV_COEFFS_PER_MB);
+  if (std::fread(mbs.data(), sizeof(dryv_mb_desc), n, f) != n) return 2;
+  if (std::fread(co.data(), 2, co.size(), f) != co.size()) return 2;
+  std::fclose(f);
+
+  dryv_recon_ctx* ctx = nullptr;
+  int st = dryv_recon_create(&ctx, 0);
+  if (st != DRYV_OK) { std::fprintf(stderr, "dryv_recon_create: %s\n", dryv_recon_strerror(st)); return 3; }
+  FILE* out = std::fopen(argv[2], "wb");
+  if (!out) return 2;
+  for (uint32_t fi = 0; fi < n_frames; fi++) {
+    dryv::Frame frame(fp, ctx);                                     // Frame::new(&slice)      decoder.rs:124
+    for (size_t a = 0; a < per; a++) {                              // slice.data(): the CABAC MB loop
+      st = frame.decode(unpack(mbs[fi * per + a], &co[(fi * per + a) * DRYV_COEFFS_PER_MB]));  // cabac/mod.rs:208
+      if (st != DRYV_OK) { std::fprintf(stderr, "decode: %s\n", dryv_recon_strerror(st)); return 4; }
+    }
+    const uint8_t* p;
+    size_t bytes;
+    st = frame.planes(&p, &bytes);                                  // write_to_yuv_file       decoder.rs:142
+    if (st != DRYV_OK) { std::fprintf(stderr, "reconstruct: %s\n", dryv_recon_strerror(st)); return 5; }
+    std::fwrite(p, 1, bytes, out);
+  }
+  std::fclose(out);
+  dryv_recon_destroy(ctx);
+  return 0;
+}
