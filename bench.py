@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2_1080p_intra_4x4", choices=sorted(synth.WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=None)
-    ap.add_argument("--cpu-sample-frames", type=int, default=100)
+    ap.add_argument("--cpu-sample-frames", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

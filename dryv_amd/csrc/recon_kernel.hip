@@ -76,10 +76,11 @@ struct WaveScratch {
   union {
     struct {
       union {
-        unsigned resTe[256];   // Intra4x4: per pixel [by*4+bx][y*4+x]: residual (lo 16) | table entry (hi 16)
+        unsigned resTe[256];   // Intra4x4: per pixel [by*4+bx][x*4+y]: prediction entry (see I4Lane)
         int16_t resB[256];     // Intra8x8 residual [y*16+x]
       };
       uint8_t tileY[17 * 32];  // luma tile with borders: row 0 = y -1, byte 3 = x -1, bytes 4..27 = x 0..23
+      int16_t resS[256];       // Intra4x4: per pixel [by*4+bx][x*4+y]: residual
     };
     int32_t g8[256];  // 8x8 transform: row-pass output of the four blocks
   };
@@ -88,8 +89,9 @@ struct WaveScratch {
   // neighbour window of the row above, fetched per macroblock: Y x = -4..27, Cb x = -4..11, Cr x = -4..11,
   // then the four bottom-row modes of macroblock B
   uint8_t up[80];
+  uint8_t pad[48];
 };
-static_assert(sizeof(WaveScratch) % 16 == 0, "scratch must keep 16-byte alignment");
+static_assert(sizeof(WaveScratch) % 64 == 0, "the transpose swizzle needs 64-byte aligned scratch");
 
 __host__ __device__ constexpr int TY(int x, int y) { return (y + 1) * 32 + (x + 4); }
 
@@ -132,7 +134,9 @@ typedef __attribute__((address_space(3))) const int* lds_i32p;
 //      transform.rs:145-146) and this is the lane holding it.
 //      d = (c * (LS << max(qp/6-4, 0)) + rnd) >> max(4-qp/6, 0)  ==  transform.rs:147-152.
 // The 4x4 transpose between the row and the column butterfly goes through LDS (trW: this lane's 16 bytes,
-// trR: its column in the quad's 64 bytes): the SIMD is VALU-bound, the LDS pipe is not.
+// trR: its column in the quad's 64 bytes). Row r of quad q sits in 16-byte chunk r ^ ((q >> 1) & 3) of the
+// quad's 64 bytes: with the plain layout the eight quads of a half-wave hit two bank groups (4-way conflicts
+// on every column read); with the swizzle they hit eight.
 // Out: r[k] = residual of the block at (x = sq, y = k) — the lane now owns COLUMN sq.
 __device__ __forceinline__ void residual4x4_quad(int a0, int a1, int a2, int a3, bool dcLane, int dcVal, int lsAddr,
                                                  unsigned qi, int trW, int trR, int r[4]) {
@@ -148,8 +152,8 @@ __device__ __forceinline__ void residual4x4_quad(int a0, int a1, int a2, int a3,
   const int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
   *LDSP(lds_i4w, trW) = i32x4{e0 + e3, e1 + e2, e1 - e2, e0 - e3};
   WAVE_SYNC();
-  const int f0 = *LDSP(lds_i32p, trR), f1 = *LDSP(lds_i32p, trR + 16), f2 = *LDSP(lds_i32p, trR + 32),
-            f3 = *LDSP(lds_i32p, trR + 48);  // f[0..3][sq]
+  const int f0 = *LDSP(lds_i32p, trR), f1 = *LDSP(lds_i32p, trR ^ 16), f2 = *LDSP(lds_i32p, trR ^ 32),
+            f3 = *LDSP(lds_i32p, trR ^ 48);  // f[0..3][sq]
   WAVE_SYNC();
   // column butterfly (transform.rs:171-181) and rounding (:183-187)
   const int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = f1 + (f3 >> 1);
@@ -193,70 +197,81 @@ __host__ __device__ constexpr int stepByHi(int t) { return (t >> 1) < 3 ? (t >> 
 // top-right 4x4 block decoded before this one inside the macroblock (by > 0): bx even, or (1,2)
 __host__ __device__ constexpr bool trInside(int bx, int by) { return (bx & 1) == 0 || (bx == 1 && by == 2); }
 
-template <int CTRL>
-__device__ __forceinline__ int dppz(int src) {  // lanes without a source read 0: lets the compiler fold the DPP
-  return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xF, 0xF, true);
-}
-
-// Intra4x4 pixel organisation: lanes 0..31, 16 lanes per block, two blocks (groups) per step.
-// The 16 lanes of a block first hold its reference samples on one line (index i'):
-//   0: L3 (dup) | 1..4: L3..L0 (left column, bottom to top) | 5: corner | 6..13: T0..T7 | 14: T7 (dup) | 15: DC
-// F[i'] = (E[i'-1] + 2E[i'] + E[i'+1] + 2) >> 2 and G[i'] = (E[i'] + E[i'+1] + 1) >> 1 come from DPP row
-// shifts; the duplicated ends give the reference's (a + 3b + 2) >> 2 corner cases for free.
+// ---- Intra4x4 pixel wavefront -------------------------------------------------------------------
+// Lanes 0..31, 16 lanes (pixels) per block, two blocks (groups) per step. Every directional mode of 8.3.1.2
+// predicts a pixel from at most three neighbouring reference samples p, q, r of the line
+//   E = [ L3 L2 L1 L0 | corner | T0..T7 ]            (left column bottom to top, corner, top row + top-right)
+// as (E[p] + 2 E[q] + E[r] + 2) >> 2:  E[i] itself = (i, i, i);  the 3-tap (E[i-1] + 2E[i] + E[i+1] + 2) >> 2
+// = (i-1, i, i+1);  the 2-tap (E[i] + E[i+1] + 1) >> 1 = (i, i+1, i)  [(2a + 2b + 2) >> 2 == (a + b + 1) >> 1].
+// The per-pixel table entry therefore is three byte offsets INTO THE LUMA TILE (relative to the block origin,
+// biased by +33) and a right shift: each pixel lane reads its three samples straight from the tile, one LDS round
+// trip per step and no cross-lane traffic. Shift 31 gives the all-zero prediction (quirk Q4); DC (bit 5) is
+// handled by a wave-uniform branch taken only on steps that contain a DC block.
 struct I4Lane {
-  int pEB;       // LDS byte address of this lane's sample relative to the group-0 block origin, no top-right block
-  int dEA;       // ... + dEA when the top-right block exists (lanes 10..15 then read T4..T7 instead of T3)
-  int pW;        // LDS byte address of this lane's pixel relative to the group-0 block origin
-  int pRT;       // LDS byte address of this lane's resTe word relative to the group-0 block's first word
-  int gb4;       // 4 * first lane of this 16-lane group
-  bool grp1, is15;
+  int pS;    // LDS byte address of tile sample "offset 0" (block origin - 33) for the group-0 block of step 0
+  int pW;    // LDS byte address of this lane's pixel relative to the group-0 block origin
+  int pEnt;  // LDS byte address of this lane's entry word relative to the group-0 block's first entry
+  int pRes;  // LDS byte address of this lane's residual relative to the group-0 block's first residual
+  bool grp1;
 };
 
-// One step of the Intra4x4 block wavefront (8.3.1.2, pred4x4.rs:10-360), statically scheduled.
-// INTERIOR: macroblocks A, B and C all exist, every availability test folds away.
+typedef __attribute__((address_space(3))) const uint8_t* lds_u8p;
+typedef __attribute__((address_space(3))) uint8_t* lds_u8w;
+typedef __attribute__((address_space(3))) const unsigned* lds_u32cp;
+typedef __attribute__((address_space(3))) const int16_t* lds_i16cp;
+
+template <int T>
+__device__ __forceinline__ void i4_fetch(const I4Lane& L, unsigned& e, int& r) {
+  constexpr int by0 = stepByLo(T), bx0 = T - 2 * by0;
+  e = *(lds_u32cp)(uintptr_t)(unsigned)(L.pEnt + (by0 * 4 + bx0) * 64);
+  r = *(lds_i16cp)(uintptr_t)(unsigned)(L.pRes + (by0 * 4 + bx0) * 32);
+}
+
+// One step of the Intra4x4 block wavefront (8.3.1.2, pred4x4.rs:10-360), statically scheduled. (e, r) = this
+// lane's entry and residual for step T, fetched during the previous step; on return they are step T+1's.
+// dcBlocks: raster bit mask of the blocks predicted in DC mode (wave-uniform).
+// INTERIOR: macroblocks A and B exist, every availability test folds away.
 template <int T, bool INTERIOR>
-__device__ __forceinline__ void i4_step(const I4Lane& L, bool mbA, bool mbB, bool mbC, int lane) {
+__device__ __forceinline__ void i4_step(const I4Lane& L, unsigned& e, int& r, unsigned dcBlocks, bool mbA, bool mbB) {
   constexpr int by0 = stepByLo(T), bx0 = T - 2 * by0;
   constexpr bool two = by0 + 1 <= stepByHi(T);
   constexpr int bx1 = two ? bx0 - 2 : bx0, by1 = two ? by0 + 1 : by0;  // group-1 block
   constexpr int oTile = TY(4 * bx0, 4 * by0);                          // tile byte offset of the block origin
-  constexpr int oRT = (by0 * 4 + bx0) * 64;                            // byte offset of the block's resTe words
-  if (!(two ? lane < 32 : lane < 16)) return;
-  typedef __attribute__((address_space(3))) const uint8_t* lds_u8p;
-  typedef __attribute__((address_space(3))) const unsigned* lds_u32p;
-  typedef __attribute__((address_space(3))) uint8_t* lds_u8w;
-  // top-right availability per group
-  const bool tr0 = by0 > 0 ? trInside(bx0, by0) : (INTERIOR ? true : (bx0 < 3 ? mbB : mbC));
-  constexpr bool tr1 = trInside(bx1, by1);
-  // (arithmetic rather than a select between two struct fields: the latter becomes an indexed scratch load)
-  const int trMask = (L.grp1 ? tr1 : tr0) ? -1 : 0;
-  const int pE = L.pEB + (L.dEA & trMask);
-  const int E = *(lds_u8p)(uintptr_t)(unsigned)(pE + oTile);
-  const unsigned rt = *(lds_u32p)(uintptr_t)(unsigned)(L.pRT + oRT);
-  const int a = E + dppz<ROW_SHL(1)>(E);  // E[i] + E[i+1]
-  const int b = E + dppz<ROW_SHR(1)>(E);  // E[i] + E[i-1]
-  const int F = (a + b + 2) >> 2;
-  const int G = (a + 1) >> 1;
-  // DC (pred4x4.rs:116-167): left column = E[1..4], top row = E[6..9]
-  const int s2 = a + dppz<ROW_SHL(2)>(a);
-  const int sumL = dppz<ROW_SHR(14)>(s2), sumT = dppz<ROW_SHR(9)>(s2);  // meaningful on lane 15
-  int dc;
-  if (INTERIOR) {
-    dc = (sumT + sumL + 4) >> 3;
-  } else {
-    const bool topAv = L.grp1 ? (by1 > 0 || mbB) : (by0 > 0 || mbB);
-    const bool leftAv = L.grp1 ? (bx1 > 0 || mbA) : (bx0 > 0 || mbA);
-    dc = (topAv && leftAv) ? (sumT + sumL + 4) >> 3 : leftAv ? (sumL + 2) >> 2 : topAv ? (sumT + 2) >> 2 : 128;
+  constexpr unsigned stepBlocks = (1u << (by0 * 4 + bx0)) | (1u << (by1 * 4 + bx1));
+  unsigned eN = 0;
+  int rN = 0;
+  if (T < 9) i4_fetch<(T < 9 ? T + 1 : 9)>(L, eN, rN);
+  if (two || !L.grp1) {
+    const int a0 = L.pS + (int)((e >> 8) & 0xff), a1 = L.pS + (int)((e >> 16) & 0xff), a2 = L.pS + (int)(e >> 24);
+    const int s0 = *(lds_u8p)(uintptr_t)(unsigned)(a0 + oTile);
+    const int s1 = *(lds_u8p)(uintptr_t)(unsigned)(a1 + oTile);
+    const int s2 = *(lds_u8p)(uintptr_t)(unsigned)(a2 + oTile);
+    int pred = (int)((unsigned)(s0 + 2 * s1 + s2 + 2) >> (e & 31u));
+    if (dcBlocks & stepBlocks) {
+      // DC (pred4x4.rs:116-167): top row = the aligned dword above the block, left column = four bytes at x = -1
+      const unsigned top = *(lds_u32cp)(uintptr_t)(unsigned)(L.pS + 1 + oTile);
+      const int l0 = *(lds_u8p)(uintptr_t)(unsigned)(L.pS + 32 + oTile), l1 = *(lds_u8p)(uintptr_t)(unsigned)(L.pS + 64 + oTile);
+      const int l2 = *(lds_u8p)(uintptr_t)(unsigned)(L.pS + 96 + oTile), l3 = *(lds_u8p)(uintptr_t)(unsigned)(L.pS + 128 + oTile);
+      const int sumT = (int)sum4(top), sumL = l0 + l1 + l2 + l3;
+      int dc;
+      if (INTERIOR) {
+        dc = (sumT + sumL + 4) >> 3;
+      } else {
+        const bool topAv = L.grp1 ? (by1 > 0 || mbB) : (by0 > 0 || mbB);
+        const bool leftAv = L.grp1 ? (bx1 > 0 || mbA) : (bx0 > 0 || mbA);
+        dc = (topAv && leftAv) ? (sumT + sumL + 4) >> 3 : leftAv ? (sumL + 2) >> 2 : topAv ? (sumT + 2) >> 2 : 128;
+      }
+      if (e & 32u) pred = dc;
+    }
+    *(lds_u8w)(uintptr_t)(unsigned)(L.pW + oTile) = (uint8_t)clip255(pred + r);
   }
-  const int packed = (L.is15 ? dc : E) | (F << 8) | (G << 16);  // byte 3 stays 0: the "no prediction" entry
-  const int got = __builtin_amdgcn_ds_bpermute(L.gb4 + (int)((rt >> 16) & 0xff), packed);
-  const int pred = (got >> (rt >> 24)) & 0xff;
-  *(lds_u8w)(uintptr_t)(unsigned)(L.pW + oTile) = (uint8_t)clip255(pred + (int)(int16_t)(rt & 0xffff));
+  e = eN;
+  r = rN;
 }
 
-// Intra4x4 macroblock: mode derivation (8.3.1.1), residual/table packing, the 10-step pixel wavefront.
+// Intra4x4 macroblock: mode derivation (8.3.1.1), entry/residual packing, the 10-step pixel wavefront.
 template <bool INTERIOR>
-__device__ __forceinline__ int i4_macroblock(WaveScratch* ws, const uint16_t* t4x, const int rl[4], int lane, int Tb, int Lb,
+__device__ __forceinline__ int i4_macroblock(WaveScratch* ws, int t4eAddr, const int rl[4], int lane, int Tb, int Lb,
                                              unsigned prevFlags, unsigned long long remBits, bool mbA, bool mbB,
                                              bool mbC) {
   // mode grid: lanes 0..15 = by*4+bx (raster)
@@ -284,57 +299,73 @@ __device__ __forceinline__ int i4_macroblock(WaveScratch* ws, const uint16_t* t4
     const int req = (int)((0x217771021ull >> (4 * M)) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
     if ((req & ~have) != 0) Mp = 9;
   }
-  // ---- residual + table entry per pixel. Strip lane (block sb, column sq) owns pixels (x = sq, y = 0..3)
+  const unsigned dcBlocks = (unsigned)__builtin_amdgcn_ballot_w64(Mp == 2) & 0xffffu;
+  // modes 3 and 7 read the top-right block's samples; without it T4..T7 := T3 (table rows 10 and 11).
+  // Top-right exists: inside the macroblock for the blocks decoded after their top-right neighbour, above it
+  // from macroblock B (C for the last column).
+  {
+    const unsigned trBlocks = 0x5750u | (INTERIOR ? 0xFu : ((mbB ? 0x7u : 0u) | (mbC ? 0x8u : 0u)));
+    if (!((trBlocks >> (lane & 15)) & 1u)) Mp = Mp == 3 ? 10 : Mp == 7 ? 11 : Mp;
+  }
+  // ---- entry + residual per pixel. Strip lane (block sb, column sq) owns pixels (x = sq, y = 0..3); both arrays
+  // are laid out [block (raster)][x][y], so a lane's four entries / residuals are contiguous
   {
     const int sq = lane & 3, sb = lane >> 2;
     const int sbx = ((sb >> 1) & 2) | (sb & 1), sby = ((sb >> 2) & 2) | ((sb >> 1) & 1);
     const int g = sby * 4 + sbx;
     const int mode = shfl(Mp, g);
-    const uint2 te = *(const uint2*)&t4x[mode * 16 + sq * 4];  // entries for (x = sq, y = 0..3)
-    unsigned* dst = &ws->resTe[g * 16 + sq];
-    dst[0] = __builtin_amdgcn_perm(te.x, (unsigned)rl[0], 0x05040100u);   // te.x lo16 : rl lo16
-    dst[4] = __builtin_amdgcn_perm(te.x, (unsigned)rl[1], 0x07060100u);   // te.x hi16 : rl lo16
-    dst[8] = __builtin_amdgcn_perm(te.y, (unsigned)rl[2], 0x05040100u);
-    dst[12] = __builtin_amdgcn_perm(te.y, (unsigned)rl[3], 0x07060100u);
+    const u32x4 te = *LDSP(lds_u4p, t4eAddr + mode * 64 + sq * 16);
+    *(u32x4*)&ws->resTe[g * 16 + sq * 4] = te;
+    // (clamped: clip255(pred + r) only sees r through [-255, 255], so 16 bits carry any int32 residual exactly)
+    const int r0 = min(max(rl[0], -512), 511), r1 = min(max(rl[1], -512), 511);
+    const int r2 = min(max(rl[2], -512), 511), r3 = min(max(rl[3], -512), 511);
+    uint2 rp;
+    rp.x = __builtin_amdgcn_perm((unsigned)r1, (unsigned)r0, 0x05040100u);
+    rp.y = __builtin_amdgcn_perm((unsigned)r3, (unsigned)r2, 0x05040100u);
+    *(uint2*)&ws->resS[g * 16 + sq * 4] = rp;
   }
   // ---- per-lane addresses of the pixel organisation
   I4Lane L;
   {
     const int li = lane & 15, g = (lane >> 4) & 1;
-    auto eo = [](int i) {  // sample i' of the line, relative to the block origin in the tile
-      return i <= 4 ? (3 - max(i - 1, 0)) * 32 - 1 : (i == 5 ? -33 : -32 + min(i - 6, 7));
-    };
+    const int px = li & 3, py = li >> 2;
     const int tileBase = (int)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ws->tileY;
     const int rtBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned*)ws->resTe;
-    // group 1 works on block (bx-2, by+1): +4 tile rows, -8 columns = +120 bytes; +2 blocks = +128 bytes of resTe
-    L.pEB = tileBase + eo(min(li, 9)) + 120 * g;  // no top-right block: T4..T7 := T3
-    L.dEA = eo(li) - eo(min(li, 9));
-    L.pW = tileBase + (li >> 2) * 32 + (li & 3) + 120 * g;
-    L.pRT = rtBase + 4 * li + 128 * g;
-    L.gb4 = (lane & ~15) * 4;
+    const int rsBase = (int)(uintptr_t)(__attribute__((address_space(3))) int16_t*)ws->resS;
+    // group 1 works on block (bx-2, by+1): +4 tile rows, -8 columns = +120 bytes; +2 raster blocks
+    L.pS = tileBase - 33 + 120 * g;
+    L.pW = tileBase + py * 32 + px + 120 * g;
+    L.pEnt = rtBase + 4 * (px * 4 + py) + 128 * g;
+    L.pRes = rsBase + 2 * (px * 4 + py) + 64 * g;
     L.grp1 = g != 0;
-    L.is15 = li == 15;
   }
   WAVE_SYNC();
-  i4_step<0, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<1, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<2, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<3, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<4, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<5, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<6, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<7, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<8, INTERIOR>(L, mbA, mbB, mbC, lane);
-  WAVE_SYNC();
-  i4_step<9, INTERIOR>(L, mbA, mbB, mbC, lane);
+#ifndef DRYV_SKIP_CHAIN  // tuning only
+  if (lane < 32) {
+    unsigned e;
+    int r;
+    i4_fetch<0>(L, e, r);
+    i4_step<0, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<1, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<2, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<3, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<4, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<5, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<6, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<7, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<8, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+    WAVE_SYNC();
+    i4_step<9, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
+  }
+#endif
   WAVE_SYNC();
   return M;
 }
@@ -400,10 +431,10 @@ struct BandShared {
 #define LT_QINFO 3328   // u16 [52]      rounding << 8 | right shift of the same formula
 #define LT_QPC 3440     // u8  [2][52]   QP'c for Cb / Cr as a function of QPY             (transform.rs:194-216)
 #define LT_LS8 3552     // u16 [6][64]   LevelScale8x8
-#define LT_T4X 4320     // u16 [10][16]  Intra4x4 gather table [mode][x][y]
-#define LT_T8 4640      // u8  [9][64]   Intra8x8 gather table
-#define LT_ZZ8 5216     // u8  [64]      raster -> 8x8 zig-zag list index
-#define LT_END 5280
+#define LT_T4E 4320     // u32 [12][16]  Intra4x4 prediction entries [mode][x][y] (9: zero, 10/11: modes 3/7 without top-right)
+#define LT_T8 5088      // u8  [9][64]   Intra8x8 gather table
+#define LT_ZZ8 5664     // u8  [64]      raster -> 8x8 zig-zag list index
+#define LT_END 5760     // (64-byte aligned: see WaveScratch)
 
 __global__ void __launch_bounds__(256, 8)
 recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_t* __restrict__ coeffs,
@@ -424,7 +455,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   uint16_t* qinfo = (uint16_t*)(lds + LT_QINFO);
   uint8_t* qpcT = lds + LT_QPC;
   uint16_t* ls8 = (uint16_t*)(lds + LT_LS8);
-  uint16_t* t4x = (uint16_t*)(lds + LT_T4X);
+  unsigned* t4e = (unsigned*)(lds + LT_T4E);
   uint8_t* t8 = lds + LT_T8;
   uint8_t* zz8i = lds + LT_ZZ8;
   WaveScratch* ws = (WaveScratch*)(lds + LT_END) + wave;
@@ -446,18 +477,22 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
     qpcT[i] = (uint8_t)(qpi - delta);
   }
   for (int i = threadIdx.x; i < 384; i += blockDim.x) ls8[i] = P.ls8[i];
-  for (int i = threadIdx.x; i < 160; i += blockDim.x) {
-    // t4x[mode][x][y]: low byte = 4 * lane index of the sample on the line (shifted by one, see I4Lane),
-    // high byte = bit offset of E / F / G in the packed word; 24 = the always-zero byte ("no prediction")
-    const int mode = i >> 4, x = (i >> 2) & 3, y = i & 3;
-    uint16_t v;
-    if (mode == 9) v = (uint16_t)(24 << 8);
-    else if (mode == 2) v = (uint16_t)(15 * 4);
+  for (int i = threadIdx.x; i < 192; i += blockDim.x) {
+    // t4e[mode][x][y] = shift | DC flag << 5 | three tile offsets (relative to the block origin, +33) << 8/16/24.
+    // P.t4 names a sample by its index j on the line E (0..3 = L3..L0, 4 = corner, 5..12 = T0..T7) and says
+    // whether the pixel is E[j], the 3-tap or the 2-tap value there (ends replicated: pred4x4.rs "3*a + b" cases)
+    const int m = i >> 4, x = (i >> 2) & 3, y = i & 3;
+    const int mode = m < 10 ? m : (m == 10 ? 3 : 7), jmax = m < 10 ? 12 : 8;
+    unsigned v;
+    if (mode == 9) v = 31u;
+    else if (mode == 2) v = 31u | 32u;
     else {
-      const int e = P.t4[mode * 16 + y * 4 + x];
-      v = (uint16_t)((((e & 31) + 1) * 4) | (((e >> 5) * 8) << 8));
+      const int en = P.t4[mode * 16 + y * 4 + x], j = en & 31, sel = en >> 5;
+      const int ja = sel == 1 ? j - 1 : j, jb = sel == 2 ? j + 1 : j, jc = sel == 1 ? j + 1 : j;
+      auto pos = [jmax](int k) { k = min(max(k, 0), jmax); return (unsigned)(k <= 3 ? (4 - k) * 32 : k - 4); };
+      v = 2u | (pos(ja) << 8) | (pos(jb) << 16) | (pos(jc) << 24);
     }
-    t4x[i] = v;
+    t4e[i] = v;
   }
   for (int i = threadIdx.x; i < 576; i += blockDim.x) t8[i] = P.t8[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) zz8i[i] = P.zz8i[i];
@@ -547,7 +582,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // chroma strips: lanes 0..31 = plane*16 + blk*4 + sq (lanes 32..63 mirror them and are never stored)
       const int cpl = (lane >> 4) & 1, ccb = (lane >> 2) & 3, ccx = ccb & 1, ccy = ccb >> 1;
       // LDS transpose slots of the residual passes (they live in the resTe area, free at that point)
-      const int trW = wsAddr + 768 + lane * 16, trR = wsAddr + 768 + (lane & ~3) * 16 + sq * 4;
+      const int trSw = (lane >> 3) & 3;  // (the scratch base is 64-byte aligned: ^ only touches the chunk bits)
+      const int trW = wsAddr + 768 + (lane & ~3) * 16 + ((sq ^ trSw) << 4);
+      const int trR = wsAddr + 768 + (lane & ~3) * 16 + (trSw << 4) + sq * 4;
       // LDS byte addresses of the four coefficients c[sq][0..3] of an Intra4x4 luma block (list base 16*blk):
       // inverse zig-zag (frame/mod.rs:185-209) as a per-lane gather. Other list layouts differ by a per-lane delta.
       const unsigned zz = (unsigned)((0xFEA9DB83C7426510ull >> (16 * sq)) & 0xffffull);  // list indices of row sq
@@ -587,7 +624,11 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // now and -- when what we already know of its progress covers this macroblock -- the loads of the neighbour
       // window too; both L2 round trips then hide under the residuals. Lanes 0..15 pixels, lane 16 the modes word
       // (window), lane 17 the progress word; all land in WaveScratch::up.
+#ifdef DRYV_NO_WAIT  // tuning only (tools/sweep.py): the dependency-free bound of the same instruction stream
+      const unsigned need = 0;
+#else
       const unsigned need = (unsigned)min(mx + 2, W);
+#endif
       const bool winEarly = upGlobal && upDone >= need;
       const bool pollEarly = upGlobal && upDone < (unsigned)W;
       if (upGlobal) {
@@ -600,7 +641,11 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // ================= residuals (need no neighbour: done before waiting for the row above) =====
       int rl[4] = {0, 0, 0, 0};  // luma residual, column organisation (kinds 0 and 2)
       int rc[4] = {0, 0, 0, 0};  // chroma residual
+#ifdef DRYV_SKIP_RESID  // tuning only
+      if (kind > 3) {
+#else
       if (kind != 3) {
+#endif
         // ---- chroma: DC 2x2 (8.5.11, trans_chroma.rs:369-415) on lanes plane*16 + blk*4 (+ sq), then AC
         {
           const int qc = (int)qpcT[cpl * 52 + qp];  // QP'c of this lane's plane
@@ -692,7 +737,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       asm volatile("" ::: "memory");
       // the coefficient buffer is free again: start the DMA of the next macroblock and fetch its record
       if (mx + 1 < W) {
+#ifndef DRYV_SKIP_DMA  // tuning only
         if (lane < 48) dma_coefficients(wsAddr, (unsigned)lane * 16u, crsrc, (mx + 1) * 768);  // (opaque lane: not hoisted/spilled)
+#endif
         desc = *(const uint4*)(mbs + mbBase + mx + 1);
       }
       asm volatile("" ::: "memory");
@@ -790,7 +837,11 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // ================= luma ======================================================================
       unsigned yword = 0;  // row strip of this lane's block, 4 pixels
       int Mcur = 2;        // derived modes on the 4x4 grid (lanes 0..15)
+#ifdef DRYV_SKIP_LUMA  // tuning only
+      if (kind == 7) {
+#else
       if (kind == 2) {
+#endif
         // Intra16x16: 8.3.3 (pred16x16.rs:79-425); lane = block sb, column sq: x = 4*sbx+sq, y = 4*sby+k
         const int x = 4 * sbx + sq;
         int pr[4] = {0, 0, 0, 0};
@@ -836,7 +887,11 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 #pragma unroll
         for (int k = 0; k < 4; k++) w |= (unsigned)clip255(pr[k] + rl[k]) << (8 * k);
         yword = quad_transpose_bytes(w, selA, selB);  // row sq of block sb: x = 4*sbx .. +3, y = 4*sby+sq
+#ifdef DRYV_SKIP_LUMA
+      } else if (kind == 8) {
+#else
       } else if (kind == 0 || kind == 1) {
+#endif
         // mode grid: lanes 0..15 = by*4+bx (raster)
         const int mbx = lane & 3, mby = (lane >> 2) & 3;
         // top border of the tile from the neighbour window; the left border is kept up to date
@@ -845,8 +900,8 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         const int Tb = (int)((upM >> (8 * mbx)) & 0xff);  // meaningful on lanes with mby == 0
         const int Lb = dpp<ROW_SHL(3)>(Mprev, Mprev);     // meaningful on lanes with mbx == 0: left MB's column 3
         if (kind == 0) {
-          if (mbA && mbC) Mcur = i4_macroblock<true>(ws, t4x, rl, lane, Tb, Lb, prevFlags, remBits, true, true, true);
-          else Mcur = i4_macroblock<false>(ws, t4x, rl, lane, Tb, Lb, prevFlags, remBits, mbA, mbB, mbC);
+          if (mbA && mbC) Mcur = i4_macroblock<true>(ws, ldsBase + LT_T4E, rl, lane, Tb, Lb, prevFlags, remBits, true, true, true);
+          else Mcur = i4_macroblock<false>(ws, ldsBase + LT_T4E, rl, lane, Tb, Lb, prevFlags, remBits, mbA, mbB, mbC);
         } else {
           // ---- Intra8x8: 8.3.2 (pred8x8.rs:152-764), four serial blocks, one pixel per lane -------
           WAVE_SYNC();
@@ -924,13 +979,17 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       if (toLds) {
         // ring entry mx replaces entry mx-RING_K, which the row below needs until it has copied the window of
         // macroblock mx-RING_K+1
+#ifndef DRYV_NO_WAIT
         while ((int)__hip_atomic_load(&bs->cons[wave + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < mx - RING_K + 2)
           __builtin_amdgcn_s_sleep(1);
+#endif
       }
       if (lane < 32) {  // chroma: row strip (plane cpl, row 4*ccy+sq, x = 4*ccx..+3)
         const bool bottom = ccy == 1 && sq == 3;
         if (bottom && toGlobal) st_sc1((unsigned*)(planeY + cOff), cword);
+#ifndef DRYV_SKIP_STORES  // tuning only
         else *(unsigned*)(planeY + cOff) = cword;
+#endif
         if (bottom && toLds) *(unsigned*)&bs->ringC[wave][cpl][slotK * 8 + 4 * ccx] = cword;
         if (ccx == 1) ws->leftC[cpl][4 * ccy + sq] = (uint8_t)(cword >> 24);
       }
@@ -938,7 +997,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       {
         const int y = 4 * sby + sq;
         if (y == 15 && toGlobal) st_sc1((unsigned*)(planeY + yOff), yword);
+#ifndef DRYV_SKIP_STORES
         else *(unsigned*)(planeY + yOff) = yword;
+#endif
         if (y == 15 && toLds) *(unsigned*)&bs->ringY[wave][slotK * 16 + 4 * sbx] = yword;
         if (sbx == 3) {
           ws->leftY[y] = (uint8_t)(yword >> 24);

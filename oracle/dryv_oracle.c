@@ -8,8 +8,8 @@
  * PARITY UNPINNED: the reference (Stuff7/dryv, /root/reference) ships no tests, golden vectors or
  * fixtures for this path, and it cannot be built here (no rustc/cargo). This file is
  * therefore a line-by-line restatement of the Rust sources, checked against hand-derived
- * known-answer vectors (tests/golden/kat_vectors.json, derived from the cited reference lines) and
- * against an independently written second restatement (oracle/spec_model.py).
+ * known-answer vectors (tests/golden/kat_vectors.json + make_kat_vectors.py, each expectation derived by
+ * hand from the cited reference lines, not produced by this file).
  *
  * Every function cites the reference lines it follows (paths relative to /root/reference).
  * Arithmetic is int64_t throughout because the reference computes in 64-bit `isize`; `>>` on

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    fp, mbs, co = synth.workload(a.workload, a.frames)
+    fp, mbs, co, _ = synth.workload(a.workload, a.frames)
     n_mbs = a.frames * fp.pic_width_in_mbs * fp.pic_height_in_mbs
     ctx = ReconContext(0)
     times, kern = [], []
