@@ -112,7 +112,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    so = path or _build.RECON_SO
+    # DRYV_RECON_LIB: tuning only (tools/pmc_variant.sh profiles -DDRYV_SKIP_* builds through bench.py)
+    so = path or os.environ.get("DRYV_RECON_LIB") or _build.RECON_SO
     if path is None and not os.path.exists(so):
         so = _build.build_recon()
     _preload_torch_hip_runtime()

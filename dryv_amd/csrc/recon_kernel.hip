@@ -624,12 +624,18 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // now and -- when what we already know of its progress covers this macroblock -- the loads of the neighbour
       // window too; both L2 round trips then hide under the residuals. Lanes 0..15 pixels, lane 16 the modes word
       // (window), lane 17 the progress word; all land in WaveScratch::up.
+      // Two levels of "the row above is far enough": need1 = it has finished macroblock mx (neighbour B, and D/A
+      // before it): enough for the modes, chroma, Intra16x16 and all of Intra4x4/8x8 except the one block that reads
+      // the top-RIGHT macroblock's samples (C), which wants need2 = macroblock mx+1. Waiting for need2 only there
+      // (and never for Intra16x16) lets the rows of a frame follow each other at ~1 instead of 2 macroblocks.
 #ifdef DRYV_NO_WAIT  // tuning only (tools/sweep.py): the dependency-free bound of the same instruction stream
-      const unsigned need = 0;
+      const unsigned need1 = 0, need2 = 0;
 #else
-      const unsigned need = (unsigned)min(mx + 2, W);
+      const unsigned need1 = (unsigned)min(mx + 1, W), need2 = (unsigned)min(mx + 2, W);
 #endif
-      const bool winEarly = upGlobal && upDone >= need;
+      bool trDone;  // the window's x = 16..23 (top-right) part is valid
+      const unsigned upDoneAtStart = upDone;
+      const bool winEarly = upGlobal && upDone >= need1;
       const bool pollEarly = upGlobal && upDone < (unsigned)W;
       if (upGlobal) {
         const unsigned* src = lane < 16 ? (const unsigned*)(planeY + wOff) : lane == 16 ? myModes - W + mx : upProg;
@@ -747,8 +753,10 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // ================= wait for the row above, fetch the neighbour window ======================
       if (upLds) {
         // row above = wave-1 of this band: poll its LDS counter, copy the window out of its ring, tell it so
-        while (__hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+        unsigned pUp;
+        while ((pUp = __hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need1)
           __builtin_amdgcn_s_sleep(1);
+        trDone = pUp >= need2;
         PHASE_STAMP(4);  // poll the row above
         if (lane < 17) {
           // dword j of the window: Y (lanes 0..7) covers x = 4j-4..4j-1, Cb/Cr (lanes 8..11 / 12..15) likewise with 8-pixel macroblocks
@@ -762,20 +770,25 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         WAVE_SYNC();
         if (lane == 0) __hip_atomic_store(&bs->cons[wave], (unsigned)(mx + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (upGlobal && !winEarly) {
-        while (upDone < need) {
+        while (upDone < need1) {
           unsigned v = 0;
           if (lane == 0) v = ld_sc1(upProg);
           upDone = (unsigned)rfl((int)v);
-          if (upDone < need) __builtin_amdgcn_s_sleep(2);
+          if (upDone < need1) __builtin_amdgcn_s_sleep(2);
         }
+        trDone = upDone >= need2;
         PHASE_STAMP(4);  // poll the row above
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: keep the loads below the poll
         if (lane < 17) {
           const unsigned* src = lane < 16 ? (const unsigned*)(planeY + wOff) : myModes - W + mx;
           ((unsigned*)ws->up)[lane] = ld_sc1(src);
         }
+      } else {
+        trDone = upDoneAtStart >= need2;  // (early window: valid as far as the row above was known to be then)
       }
       WAVE_SYNC();
+      // Intra4x4 / Intra8x8 with a top-right macroblock: make sure its bottom line is there before the luma blocks
+      const bool lateTR = (kind == 0 || kind == 1) && mbC && !trDone;
       wOff += lane < 8 ? 16u : 8u;
       const uint8_t* up = ws->up;
       PHASE_STAMP(5);  // neighbour window fetch
@@ -894,6 +907,25 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 #endif
         // mode grid: lanes 0..15 = by*4+bx (raster)
         const int mbx = lane & 3, mby = (lane >> 2) & 3;
+        if (lateTR) {
+          // fetch x = 16..23 of the row above (window dwords 5 and 6: the bottom line of macroblock mx+1) now
+          if (upLds) {
+            while (__hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need2)
+              __builtin_amdgcn_s_sleep(1);
+            if (lane == 5 || lane == 6)
+              ((unsigned*)ws->up)[lane] = *(const unsigned*)&bs->ringY[wave - 1][((mx + 1) & (RING_K - 1)) * 16 + (lane - 5) * 4];
+          } else {
+            while (upDone < need2) {
+              unsigned v = 0;
+              if (lane == 0) v = ld_sc1(upProg);
+              upDone = (unsigned)rfl((int)v);
+              if (upDone < need2) __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 5 || lane == 6) ((unsigned*)ws->up)[lane] = ld_sc1((const unsigned*)(planeY + (wOff - 16u)));
+          }
+          WAVE_SYNC();
+        }
         // top border of the tile from the neighbour window; the left border is kept up to date
         if (lane < 25) ws->tileY[TY(lane - 1, -1)] = up[UPY(lane - 1)];
         const unsigned upM = mbB ? *(const unsigned*)&up[UPM] : 0x02020202u;

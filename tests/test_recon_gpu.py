@@ -89,6 +89,33 @@ def test_random_parity(recon_ctx, case):
     assert_parity(recon_ctx, fp, frames, mbs, co)
 
 
+def test_fuzz_geometries_and_configs(recon_ctx):
+    """60 seeded random (geometry, mix, qp range, chroma offsets, scaling lists, legality) combinations:
+    ragged sizes (1..21 x 1..13 macroblocks: rows that are not a multiple of the 4-row band, widths below the
+    top-right reach, single rows/columns), 1..3 frames."""
+    rng = np.random.default_rng(20261004)
+    for k in range(60):
+        W, H, frames = int(rng.integers(1, 22)), int(rng.integers(1, 14)), int(rng.integers(1, 4))
+        i4 = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+        i8 = float(rng.choice([0.0, 0.3])) if i4 < 1.0 else 0.0
+        i8 = min(i8, 1.0 - i4)
+        lo = int(rng.integers(0, 40))
+        flat = rng.random() < 0.6
+        fkw = dict(transform_8x8=i8 > 0, cqo_cb=int(rng.integers(-12, 13)), cqo_cr=int(rng.integers(-12, 13)))
+        if not flat:
+            fkw.update(scaling4x4=rng.integers(4, 48, size=(6, 16)), scaling8x8=rng.integers(4, 48, size=(6, 64)))
+        skw = dict(i4x4=i4, i8x8=i8, qp=(lo, int(rng.integers(lo, 52))), coded=float(rng.choice([0.2, 0.6, 1.0])),
+                   max_level=int(rng.choice([15, 300, 2047])) if flat else 200,
+                   legal_modes_only=bool(rng.random() < 0.7), prev_flag=float(rng.choice([0.1, 0.5, 0.9])))
+        fp = abi.make_frame_params(W, H, **fkw)
+        mbs, co = synth.generate(fp, synth.config(**skw), 1000 + k, k, frames)
+        try:
+            assert_parity(recon_ctx, fp, frames, mbs, co)
+        except AssertionError as e:
+            raise AssertionError("fuzz case %d (W=%d H=%d frames=%d %r %r): %s" % (k, W, H, frames, skw, {
+                kk: vv for kk, vv in fkw.items() if not hasattr(vv, "shape")}, e))
+
+
 def test_nonflat_scaling_lists(recon_ctx):
     """Non-flat matrices: chroma re-uses the luma (list 0) LevelScale tables — quirk Q3."""
     rng = np.random.default_rng(5)
