@@ -168,11 +168,12 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   if (st != DRYV_OK) return st;
   hipError_t e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
-  // Persistent grid: 4-wave workgroups, 8 per CU; each workgroup keeps claiming 4-row bands until none are left,
-  // so a smaller grid is merely slower and never incorrect.
+  // Persistent grid: 32 waves per CU (8 per SIMD at 64 VGPRs); each band slot of a workgroup keeps claiming 4-row
+  // bands until none are left, so a smaller grid is merely slower and never incorrect.
+  const int bpb = dryv::recon_bands_per_block();
   const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
-  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * 8;
-  if (grid > total_bands) grid = total_bands;
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * 8 / bpb;
+  if (grid > (total_bands + bpb - 1) / bpb) grid = (total_bands + bpb - 1) / bpb;
   if (grid < 1) grid = 1;
   e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");

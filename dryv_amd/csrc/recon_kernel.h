@@ -25,7 +25,9 @@ struct KParams {
 // Device workspace a launch needs (task counter, per-row progress words, bottom-row modes).
 size_t recon_workspace_bytes(int W, int H, int n_frames);
 hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, int grid, hipStream_t stream);
-// grid = number of 256-thread workgroups (4 independent waves each); any grid >= 1 is correct.
+// Bands (4 consecutive macroblock rows, one per wave) a workgroup works on at a time.
+int recon_bands_per_block();
+// grid = number of workgroups (recon_bands_per_block() x 4 waves each); any grid >= 1 is correct.
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv,
                         unsigned* d_status, void* d_workspace, int grid, hipStream_t stream);
 

@@ -90,6 +90,10 @@ struct WaveScratch {
   // then the four bottom-row modes of macroblock B
   uint8_t up[80];
   uint8_t pad[48];
+  // Store staging: a macroblock contributes 16 B (luma) / 8 B (chroma) per pixel row, and partial-line stores
+  // cost the memory system a full request each. Rows are collected here and stored 32 B at a time.
+  uint8_t stageY[16][32];    // luma rows of macroblocks (mx & ~1), (mx | 1)
+  uint8_t stageC[2][8][32];  // chroma rows of macroblocks (mx & ~3) .. (mx | 3)
 };
 static_assert(sizeof(WaveScratch) % 64 == 0, "the transpose swizzle needs 64-byte aligned scratch");
 
@@ -411,12 +415,20 @@ __device__ __forceinline__ void dma_window(int ldsAddr, const unsigned* src) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1" : : "s"(ldsAddr), "v"(src) : "memory");
 }
 
-#define BAND 4     // rows per band = waves per workgroup
-#define RING_K 16  // macroblocks of bottom line each row keeps in LDS for the row below (power of two)
+#define BAND 4     // rows per band = waves that hand rows to each other through LDS
+#ifndef WG_BANDS
+#define WG_BANDS 2 // independent bands per workgroup: they share nothing but the constant tables (5.7 KB)
+#endif
+#ifndef RING_K
+#define RING_K 8   // macroblocks of bottom line each row keeps in LDS for the row below (power of two)
+#endif
 struct BandShared {
   unsigned prog[BAND];  // prog[w]: macroblocks of wave w's row finished and present in its ring
   unsigned cons[BAND];  // cons[w]: macroblocks whose neighbour window wave w has copied out of wave w-1's ring
-  unsigned task, pad[3];
+  unsigned task;    // the band being processed
+  unsigned seq;     // claim number of `task` (band-local barrier: waves 1..3 wait for it to advance)
+  unsigned arrive;  // waves of the band that finished claim number seq-1, cumulative
+  unsigned pad;
   uint8_t ringY[BAND][RING_K * 16];     // bottom luma line, macroblock e at (e % RING_K) * 16
   uint8_t ringC[BAND][2][RING_K * 8];   // bottom chroma lines
   unsigned ringM[BAND][RING_K];         // bottom-row prediction modes
@@ -436,7 +448,7 @@ struct BandShared {
 #define LT_ZZ8 5664     // u8  [64]      raster -> 8x8 zig-zag list index
 #define LT_END 5760     // (64-byte aligned: see WaveScratch)
 
-__global__ void __launch_bounds__(256, 8)
+__global__ void __launch_bounds__(64 * BAND * WG_BANDS, 8)  // (threads, waves per SIMD)
 recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_t* __restrict__ coeffs,
              uint8_t* __restrict__ yuv, unsigned* __restrict__ status, unsigned* __restrict__ rowProg,
              unsigned* __restrict__ rowModes, unsigned* __restrict__ taskCounter
@@ -447,7 +459,8 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane0 = threadIdx.x & 63;
   int lane = lane0;
-  const int wave = rfl(threadIdx.x >> 6);
+  const int wgWave = rfl(threadIdx.x >> 6);
+  const int wave = wgWave & (BAND - 1);  // position in the band
   const int W = P.W, H = P.H;
 
   // ---- LDS tables (built once per workgroup) -------------------------------------------------------
@@ -458,8 +471,12 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   unsigned* t4e = (unsigned*)(lds + LT_T4E);
   uint8_t* t8 = lds + LT_T8;
   uint8_t* zz8i = lds + LT_ZZ8;
-  WaveScratch* ws = (WaveScratch*)(lds + LT_END) + wave;
-  BandShared* bs = (BandShared*)(lds + LT_END + BAND * sizeof(WaveScratch));
+  WaveScratch* ws = (WaveScratch*)(lds + LT_END) + wgWave;
+  BandShared* bs = (BandShared*)(lds + LT_END + WG_BANDS * BAND * sizeof(WaveScratch)) + (wgWave / BAND);
+  if (wave == 0 && lane0 == 0) {
+    bs->seq = 0;
+    bs->arrive = 0;
+  }
 
   for (int i = threadIdx.x; i < 52 * 16; i += blockDim.x) {
     const int qp = i >> 4, qd = qp / 6, qm = qp - 6 * qd;
@@ -511,13 +528,31 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   const int wsAddr = (int)(uintptr_t)(__attribute__((address_space(3))) WaveScratch*)ws;
   const unsigned bandsPerFrame = (unsigned)(H + BAND - 1) / BAND;
   const unsigned totalBands = (unsigned)P.n_frames * bandsPerFrame;
-  bool firstTask = true;
+  // The waves of a band synchronise among themselves only (LDS counters, no workgroup barrier: the other band of
+  // the workgroup runs on its own schedule). Claim k: every wave bumps `arrive` when it is done with claim k-1;
+  // wave 0 waits for all four, resets the hand-off counters, takes the next band off the queue and publishes it
+  // with seq = k; the others wait for seq.
+  unsigned claimNo = 0;
   for (;;) {
-    // ---- claim the next band (the first one is this workgroup's index: the queue counter starts at gridDim) --
-    if (threadIdx.x == 0) bs->task = firstTask ? blockIdx.x : atomicAdd(taskCounter, 1u);
-    if (threadIdx.x < 2 * BAND) bs->prog[threadIdx.x] = 0;  // prog[] and cons[] are adjacent
-    firstTask = false;
-    __syncthreads();
+    claimNo++;
+    if (wave == 0) {
+      if (lane0 == 0) {
+        while (__hip_atomic_load(&bs->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < BAND * (claimNo - 1))
+          __builtin_amdgcn_s_sleep(1);
+      }
+      WAVE_SYNC();
+      if (lane0 < 2 * BAND) bs->prog[lane0] = 0;  // prog[] and cons[] are adjacent
+      // (the first band is the workgroup's own index: the queue counter starts at WG_BANDS * gridDim)
+      if (lane0 == 0) bs->task = claimNo == 1 ? blockIdx.x * WG_BANDS + (unsigned)(wgWave / BAND) : atomicAdd(taskCounter, 1u);
+      WAVE_SYNC();
+      if (lane0 == 0) __hip_atomic_store(&bs->seq, claimNo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      if (lane0 == 0) {
+        while (__hip_atomic_load(&bs->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < claimNo)
+          __builtin_amdgcn_s_sleep(1);
+      }
+      WAVE_SYNC();
+    }
     const unsigned task = (unsigned)rfl((int)bs->task);  // wave-uniform: everything derived from it stays scalar
     PHASE_STAMP(0);  // claim
     if (task >= totalBands) break;
@@ -569,6 +604,8 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
     uint4 desc = *(const uint4*)(mbs + mbBase);
 
     int Mprev = 2;  // derived modes of the macroblock to the left, on the 4x4 grid (lanes 0..15)
+    int nStores = 0;  // plain stores issued after the previous macroblock's coefficient DMA (wave-uniform)
+    const unsigned offCbS = (unsigned)W * H * 256u, offCrS = offCbS + (unsigned)W * H * 64u;
 
     for (int mx = 0; mx < W; mx++) {
       // Per-lane constants are recomputed per macroblock from an opaque lane id: keeping them (and the
@@ -608,15 +645,16 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       const bool mbA = mx > 0, mbC = mbB && (mx + 1 < W);
 
       // The DMA of this macroblock's coefficients must have landed. vmcnt is ONE in-order counter for loads,
-      // stores and LDS-DMA, so the wait is counted: after the DMA a wave inside a band issues exactly its two
-      // plain pixel stores, and "all but the 2 youngest operations done" covers the DMA without waiting for them.
-      // A band's LAST row drains completely instead: its write-through stores of macroblock mx-1 must have
+      // stores and LDS-DMA, so the wait is counted: after the DMA a wave inside a band issued nStores (0..2) plain
+      // row-segment stores, and "all but the nStores youngest operations done" covers the DMA without waiting for
+      // them. A band's LAST row drains completely instead: its write-through stores of macroblock mx-1 must have
       // retired before that macroblock is published to the band below, and publishing early keeps the ramp of
-      // the 27-row wavefront at launch short. (Macroblock 0 of a row: nothing was issued after its DMA.)
+      // the 27-row wavefront at launch short.
       PHASE_STAMP(1);  // record decode, constants
       // (the builtin, not inline asm: hipcc's wait-count pass then accounts for it)
-      if (mx == 0 || toGlobal) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      else __builtin_amdgcn_s_waitcnt(0x0F72);                      // vmcnt(2)
+      if (toGlobal || nStores == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      else if (nStores == 1) __builtin_amdgcn_s_waitcnt(0x0F71);        // vmcnt(1)
+      else __builtin_amdgcn_s_waitcnt(0x0F72);                           // vmcnt(2)
       asm volatile("" ::: "memory");
       PHASE_STAMP(2);  // wait for the coefficient DMA
       if (toGlobal && mx > 0 && lane == 0) st_sc1(myProg, (unsigned)mx);
@@ -1016,12 +1054,11 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           __builtin_amdgcn_s_sleep(1);
 #endif
       }
+      const bool lastMb = mx + 1 == W;
       if (lane < 32) {  // chroma: row strip (plane cpl, row 4*ccy+sq, x = 4*ccx..+3)
         const bool bottom = ccy == 1 && sq == 3;
         if (bottom && toGlobal) st_sc1((unsigned*)(planeY + cOff), cword);
-#ifndef DRYV_SKIP_STORES  // tuning only
-        else *(unsigned*)(planeY + cOff) = cword;
-#endif
+        *(unsigned*)&ws->stageC[cpl][4 * ccy + sq][8 * (mx & 3) + 4 * ccx] = cword;
         if (bottom && toLds) *(unsigned*)&bs->ringC[wave][cpl][slotK * 8 + 4 * ccx] = cword;
         if (ccx == 1) ws->leftC[cpl][4 * ccy + sq] = (uint8_t)(cword >> 24);
       }
@@ -1029,9 +1066,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       {
         const int y = 4 * sby + sq;
         if (y == 15 && toGlobal) st_sc1((unsigned*)(planeY + yOff), yword);
-#ifndef DRYV_SKIP_STORES
-        else *(unsigned*)(planeY + yOff) = yword;
-#endif
+        *(unsigned*)&ws->stageY[y][16 * (mx & 1) + 4 * sbx] = yword;
         if (y == 15 && toLds) *(unsigned*)&bs->ringY[wave][slotK * 16 + 4 * sbx] = yword;
         if (sbx == 3) {
           ws->leftY[y] = (uint8_t)(yword >> 24);
@@ -1039,6 +1074,26 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         }
       }
       yOff += 16;
+      // flush the staged rows: lane = (row, 8-byte segment); 32 contiguous bytes per pixel row and store
+      nStores = 0;
+#ifndef DRYV_SKIP_STORES  // tuning only
+      if ((mx & 1) || lastMb) {
+        WAVE_SYNC();
+        const int row = lane >> 2, seg = lane & 3;
+        const uint2 v = *(const uint2*)&ws->stageY[row][8 * seg];
+        const unsigned off = (unsigned)(r * 16 + row) * pitchY + 16u * (unsigned)(mx & ~1) + 8u * seg;
+        if ((mx & 1) || seg < 2) *(uint2*)(planeY + off) = v;
+        nStores++;
+      }
+      if ((mx & 3) == 3 || lastMb) {
+        WAVE_SYNC();
+        const int pl = lane >> 5, row = (lane >> 2) & 7, seg = lane & 3;
+        const uint2 v = *(const uint2*)&ws->stageC[pl][row][8 * seg];
+        const unsigned off = (pl ? offCrS : offCbS) + (unsigned)(r * 8 + row) * pitchC + 8u * (unsigned)((mx & ~3) + seg);
+        if (seg <= (mx & 3)) *(uint2*)(planeY + off) = v;
+        nStores++;
+      }
+#endif
       // bottom-row modes (grid lanes 12..15) for the row below; the whole grid for the macroblock to the right
       if (toGlobal && lane == 0) st_sc1(myModes + mx, m4);
       if (toLds) {
@@ -1057,17 +1112,21 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
     }
     PHASE_STAMP(9);  // row tail
     }  // r < H
-    __syncthreads();  // the band is done: its ring and counters may be reused
+    // this wave is done with the band: its ring and counters may be reused once all four said so
+    WAVE_SYNC();
+    if (lane0 == 0) __hip_atomic_fetch_add(&bs->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 #ifdef DRYV_PHASE_PROFILE
   if (lane0 == 0) {
-    const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const size_t gw = (size_t)blockIdx.x * (blockDim.x >> 6) + wgWave;
     for (int i = 0; i < 10; i++) phaseOut[gw * 10 + i] = phaseAcc[i];
   }
 #endif
 }
 
-size_t recon_lds_bytes(int wavesPerBlock) { return LT_END + (size_t)wavesPerBlock * sizeof(WaveScratch) + sizeof(BandShared); }
+int recon_bands_per_block() { return WG_BANDS; }
+
+size_t recon_lds_bytes() { return LT_END + (size_t)WG_BANDS * BAND * sizeof(WaveScratch) + WG_BANDS * sizeof(BandShared); }
 
 size_t recon_workspace_bytes(int W, int H, int n_frames) {
   // [task counter | pad to 256] [row progress: n_frames*H u32 | pad to 256] [bottom-row modes: n_mbs u32]
@@ -1086,14 +1145,14 @@ static size_t prog_bytes(const KParams& P) { return (((size_t)P.n_frames * P.H *
 hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, int grid, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_workspace, 0, 256 + prog_bytes(P), stream);
   if (e != hipSuccess) return e;
-  // every workgroup starts on the band equal to its index; the queue hands out the rest
-  return hipMemsetD32Async((hipDeviceptr_t)d_workspace, grid, 1, stream);
+  // every band slot of every workgroup starts on the band equal to its index; the queue hands out the rest
+  return hipMemsetD32Async((hipDeviceptr_t)d_workspace, grid * WG_BANDS, 1, stream);
 }
 
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
                         void* d_workspace, int grid, hipStream_t stream) {
-  const int wavesPerBlock = 4;
-  const size_t ldsBytes = recon_lds_bytes(wavesPerBlock);
+  const int wavesPerBlock = BAND * WG_BANDS;
+  const size_t ldsBytes = recon_lds_bytes();
   unsigned char* wsb = (unsigned char*)d_workspace;
   hipLaunchKernelGGL(recon_kernel, dim3(grid), dim3(wavesPerBlock * 64), ldsBytes, stream, P,
                      (const dryv_mb_desc*)d_mbs, (const int16_t*)d_coeffs, (uint8_t*)d_yuv, d_status,

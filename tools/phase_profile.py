@@ -42,7 +42,7 @@ def main():
         assert lib.dryv_recon_sync(h) == 0
     ms = C.c_float()
     lib.dryv_recon_last_kernel_ms(h, C.byref(ms))
-    n_waves = min(2048, (n * 68 + 3) // 4) * 4
+    n_waves = min(1024, (n * 68 + 7) // 8) * 8
     out = np.zeros((n_waves, 10), dtype=np.uint64)
     assert lib.dryv_recon_debug_phases(h, C.byref(fp), C.c_uint32(n), C.c_int(n_waves), out.ctypes.data_as(C.c_void_p)) == 0
     tot = out.sum(axis=0).astype(np.float64)
