@@ -50,8 +50,8 @@ def cpu_baseline(fp, mbs, coeffs, n_frames, gpu_out, frame_bytes, sample_frames)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2_1080p_intra_4x4", choices=sorted(synth.WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=None)
     ap.add_argument("--cpu-sample-frames", type=int, default=300)

@@ -172,7 +172,7 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   // bands until none are left, so a smaller grid is merely slower and never incorrect.
   const int bpb = dryv::recon_bands_per_block();
   const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
-  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * 8 / bpb;
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::recon_blocks_per_cu();
   if (grid > (total_bands + bpb - 1) / bpb) grid = (total_bands + bpb - 1) / bpb;
   if (grid < 1) grid = 1;
   e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);

@@ -27,6 +27,8 @@ size_t recon_workspace_bytes(int W, int H, int n_frames);
 hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, int grid, hipStream_t stream);
 // Bands (4 consecutive macroblock rows, one per wave) a workgroup works on at a time.
 int recon_bands_per_block();
+// Workgroups the kernel is compiled to keep resident per CU (register budget).
+int recon_blocks_per_cu();
 // grid = number of workgroups (recon_bands_per_block() x 4 waves each); any grid >= 1 is correct.
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv,
                         unsigned* d_status, void* d_workspace, int grid, hipStream_t stream);

@@ -416,6 +416,9 @@ __device__ __forceinline__ void dma_window(int ldsAddr, const unsigned* src) {
 }
 
 #define BAND 4     // rows per band = waves that hand rows to each other through LDS
+#ifndef DRYV_WPS
+#define DRYV_WPS 8  // resident waves per SIMD the kernel is compiled for (512 VGPRs / DRYV_WPS each)
+#endif
 #ifndef WG_BANDS
 #define WG_BANDS 2 // independent bands per workgroup: they share nothing but the constant tables (5.7 KB)
 #endif
@@ -448,7 +451,7 @@ struct BandShared {
 #define LT_ZZ8 5664     // u8  [64]      raster -> 8x8 zig-zag list index
 #define LT_END 5760     // (64-byte aligned: see WaveScratch)
 
-__global__ void __launch_bounds__(64 * BAND * WG_BANDS, 8)  // (threads, waves per SIMD)
+__global__ void __launch_bounds__(64 * BAND * WG_BANDS, DRYV_WPS)  // (threads, waves per SIMD)
 recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_t* __restrict__ coeffs,
              uint8_t* __restrict__ yuv, unsigned* __restrict__ status, unsigned* __restrict__ rowProg,
              unsigned* __restrict__ rowModes, unsigned* __restrict__ taskCounter
@@ -1125,6 +1128,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 }
 
 int recon_bands_per_block() { return WG_BANDS; }
+int recon_blocks_per_cu() { return DRYV_WPS * 4 / (BAND * WG_BANDS); }
 
 size_t recon_lds_bytes() { return LT_END + (size_t)WG_BANDS * BAND * sizeof(WaveScratch) + WG_BANDS * sizeof(BandShared); }
 
