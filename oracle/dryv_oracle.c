@@ -9,7 +9,9 @@
  * fixtures for this path, and it cannot be built here (no rustc/cargo). This file is
  * therefore a line-by-line restatement of the Rust sources, checked against hand-derived
  * known-answer vectors (tests/golden/kat_vectors.json + make_kat_vectors.py, each expectation derived by
- * hand from the cited reference lines, not produced by this file).
+ * hand from the cited reference lines, not produced by this file) and against a second restatement with a
+ * different structure and source (oracle/spec_model.py: written from the H.264 clauses, the reference's
+ * quirks patched in; tests/test_spec_model.py). Neither pins it to the reference's actual output.
  *
  * Every function cites the reference lines it follows (paths relative to /root/reference).
  * Arithmetic is int64_t throughout because the reference computes in 64-bit `isize`; `>>` on
