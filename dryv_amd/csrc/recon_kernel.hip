@@ -416,6 +416,12 @@ __device__ __forceinline__ void dma_window(int ldsAddr, const unsigned* src) {
 }
 
 #define BAND 4     // rows per band = waves that hand rows to each other through LDS
+#ifndef DRYV_POLL_SLEEP
+#define DRYV_POLL_SLEEP 8  // s_sleep argument (x64 clocks) between two polls of a neighbouring wave's LDS counter
+#endif
+#ifndef DRYV_GPOLL_SLEEP
+#define DRYV_GPOLL_SLEEP 2  // the same between two polls of a progress word in L2 (band boundaries)
+#endif
 #ifndef DRYV_WPS
 #define DRYV_WPS 8  // resident waves per SIMD the kernel is compiled for (512 VGPRs / DRYV_WPS each)
 #endif
@@ -545,8 +551,10 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
       WAVE_SYNC();
       if (lane0 < 2 * BAND) bs->prog[lane0] = 0;  // prog[] and cons[] are adjacent
-      // (the first band is the workgroup's own index: the queue counter starts at WG_BANDS * gridDim)
-      if (lane0 == 0) bs->task = claimNo == 1 ? blockIdx.x * WG_BANDS + (unsigned)(wgWave / BAND) : atomicAdd(taskCounter, 1u);
+      // Every band, the first one included, comes off the one queue: a band's predecessor (same frame, band
+      // above) has a smaller number, so it was claimed earlier by a workgroup that is running or done -- no
+      // deadlock however few workgroups the device keeps resident.
+      if (lane0 == 0) bs->task = atomicAdd(taskCounter, 1u);
       WAVE_SYNC();
       if (lane0 == 0) __hip_atomic_store(&bs->seq, claimNo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
@@ -796,7 +804,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         // row above = wave-1 of this band: poll its LDS counter, copy the window out of its ring, tell it so
         unsigned pUp;
         while ((pUp = __hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need1)
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
         trDone = pUp >= need2;
         PHASE_STAMP(4);  // poll the row above
         if (lane < 17) {
@@ -815,7 +823,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           unsigned v = 0;
           if (lane == 0) v = ld_sc1(upProg);
           upDone = (unsigned)rfl((int)v);
-          if (upDone < need1) __builtin_amdgcn_s_sleep(2);
+          if (upDone < need1) __builtin_amdgcn_s_sleep(DRYV_GPOLL_SLEEP);
         }
         trDone = upDone >= need2;
         PHASE_STAMP(4);  // poll the row above
@@ -952,7 +960,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
           // fetch x = 16..23 of the row above (window dwords 5 and 6: the bottom line of macroblock mx+1) now
           if (upLds) {
             while (__hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need2)
-              __builtin_amdgcn_s_sleep(1);
+              __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
             if (lane == 5 || lane == 6)
               ((unsigned*)ws->up)[lane] = *(const unsigned*)&bs->ringY[wave - 1][((mx + 1) & (RING_K - 1)) * 16 + (lane - 5) * 4];
           } else {
@@ -960,7 +968,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
               unsigned v = 0;
               if (lane == 0) v = ld_sc1(upProg);
               upDone = (unsigned)rfl((int)v);
-              if (upDone < need2) __builtin_amdgcn_s_sleep(2);
+              if (upDone < need2) __builtin_amdgcn_s_sleep(DRYV_GPOLL_SLEEP);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (lane == 5 || lane == 6) ((unsigned*)ws->up)[lane] = ld_sc1((const unsigned*)(planeY + (wOff - 16u)));
@@ -1054,7 +1062,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         // macroblock mx-RING_K+1
 #ifndef DRYV_NO_WAIT
         while ((int)__hip_atomic_load(&bs->cons[wave + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < mx - RING_K + 2)
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
 #endif
       }
       const bool lastMb = mx + 1 == W;
@@ -1147,10 +1155,8 @@ static size_t prog_bytes(const KParams& P) { return (((size_t)P.n_frames * P.H *
 // the task counter and the row-progress words start every launch at zero (the modes need no reset:
 // every word is written before it is read)
 hipError_t recon_reset_workspace(const KParams& P, void* d_workspace, int grid, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(d_workspace, 0, 256 + prog_bytes(P), stream);
-  if (e != hipSuccess) return e;
-  // every band slot of every workgroup starts on the band equal to its index; the queue hands out the rest
-  return hipMemsetD32Async((hipDeviceptr_t)d_workspace, grid * WG_BANDS, 1, stream);
+  (void)grid;
+  return hipMemsetAsync(d_workspace, 0, 256 + prog_bytes(P), stream);
 }
 
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,

@@ -236,3 +236,26 @@ def test_full_batch_properties_c2(recon_ctx):
     idx = (perm[:, None] * per + np.arange(per)[None, :]).ravel()
     out3 = recon_ctx.reconstruct(fp, n, mbs[idx], co[idx])
     assert np.array_equal(out3.reshape(n, fb), out1.reshape(n, fb)[perm])
+
+
+def test_oversubscribed_grid_completes(tmp_path):
+    """More workgroups than the device keeps resident (DRYV_RECON_GRID=1100 x 2 bands > 1024 resident x 2): every
+    band is claimed from the one queue, so late-starting workgroups can never hold a band others wait for.
+    Runs in a child process under a timeout: a scheduling deadlock must fail the test, not hang the suite."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import oracle\n"
+        "from dryv_amd import synth, ReconContext\n"
+        "fp, mbs, co, n = synth.workload('C2_1080p_intra_4x4', n_frames=300)\n"
+        "got = ReconContext(0).reconstruct(fp, n, mbs, co)\n"
+        "per = 8160\n"
+        "st, want = oracle.reconstruct(fp, 4, mbs[-4 * per:], co[-4 * per:])\n"
+        "assert st == 0 and np.array_equal(got[-4 * per * 384:], want)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for grid in ("1100", "3000", "7"):
+        env = dict(os.environ, DRYV_RECON_GRID=grid)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0 and "ok" in r.stdout, (grid, r.stdout[-500:], r.stderr[-2000:])
