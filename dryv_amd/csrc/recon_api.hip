@@ -341,7 +341,7 @@ const char* dryv_recon_last_device_error(dryv_recon_ctx* ctx) { return ctx ? ctx
 /* diagnostic build only: copies the per-wave phase cycle sums of the last launch (n_waves x 10 u64) */
 int dryv_recon_debug_phases(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, int n_waves,
                             unsigned long long* out) {
-  if (!ctx || !fp || !out || n_waves > 65536) return DRYV_E_INVALID;
+  if (!ctx || !fp || !out || n_waves > 65536) return DRYV_E_INVALID;  /* rows of the timeline follow at slot 16384 */
   const size_t prog = (((size_t)n_frames * fp->pic_height_in_mbs * 4) + 255) & ~(size_t)255;
   const size_t off = ((256 + prog + (size_t)n_frames * fp->pic_width_in_mbs * fp->pic_height_in_mbs * 4) + 255) & ~(size_t)255;
   hipError_t e = hipMemcpy(out, (unsigned char*)ctx->d_work + off, (size_t)n_waves * 80, hipMemcpyDeviceToHost);

@@ -570,6 +570,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
     const int bandRow = (int)(task / (unsigned)P.n_frames);
     const int f = (int)(task - (unsigned)bandRow * (unsigned)P.n_frames);
     const int r = bandRow * BAND + wave;
+#ifdef DRYV_PHASE_PROFILE
+    const unsigned long long rowT0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same on every XCD
+#endif
     if (r < H) {
     // where the row above comes from, and who reads this row's bottom line
     const bool upLds = wave > 0;                       // row r-1 is wave-1 of this band: LDS ring
@@ -1122,6 +1125,14 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       if (lane0 == 0) st_sc1(myProg, (unsigned)W);
     }
     PHASE_STAMP(9);  // row tail
+#ifdef DRYV_PHASE_PROFILE
+    if (lane0 == 0 && task * BAND + wave < 49152u - 16u) {  // per-row timeline (tools/timeline.py), after the per-wave sums
+      unsigned long long* tl = phaseOut + (size_t)(16384u + task * BAND + wave) * 10;
+      tl[0] = rowT0;
+      tl[1] = __builtin_amdgcn_s_memrealtime();
+      tl[2] = (unsigned long long)blockIdx.x * 8 + wgWave;
+    }
+#endif
     }  // r < H
     // this wave is done with the band: its ring and counters may be reused once all four said so
     WAVE_SYNC();
