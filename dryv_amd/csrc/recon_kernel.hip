@@ -416,6 +416,11 @@ __device__ __forceinline__ void dma_window(int ldsAddr, const unsigned* src) {
 }
 
 #define BAND 4     // rows per band = waves that hand rows to each other through LDS
+#ifdef DRYV_NO_I8X8  // tuning only: what the Intra8x8 paths cost the other macroblock kinds (registers, code size)
+constexpr bool HAS_I8 = false;
+#else
+constexpr bool HAS_I8 = true;
+#endif
 #ifndef DRYV_POLL_SLEEP
 #define DRYV_POLL_SLEEP 8  // s_sleep argument (x64 clocks) between two polls of a neighbouring wave's LDS counter
 #endif
@@ -588,6 +593,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
     unsigned* myModes = rowModes + mbBase;
     const bool mbB = r > 0;
     unsigned upDone = 0;  // what we know of the row above's progress
+    int consKnown = 0;    // ... and of the row below's consumption of our ring
 
     // ---- per-row per-lane pointers, advanced by a constant stride per macroblock -----------------
     // luma store: lane (block sb, row sq of the block) owns pixels x = 4*sbx..+3 of pixel row 16r + 4*sby + sq
@@ -755,7 +761,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
 
       // 8x8 blocks: 8.5.13 (pred8x8.rs:51-150). lanes 0..31 = (blk8, row) then (blk8, column).
-      if (kind == 1) {
+      if (HAS_I8 && kind == 1) {
         const int b8 = (lane >> 3) & 3, i = lane & 7;
         int dd[8], oo[8];
         if (lane < 32) {
@@ -805,10 +811,12 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       // ================= wait for the row above, fetch the neighbour window ======================
       if (upLds) {
         // row above = wave-1 of this band: poll its LDS counter, copy the window out of its ring, tell it so
-        unsigned pUp;
-        while ((pUp = __hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need1)
-          __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
-        trDone = pUp >= need2;
+        // (upDone caches the last value read: while the row above is ahead, no LDS round trip is spent on the poll)
+        while (upDone < need1) {
+          upDone = (unsigned)rfl((int)__hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (upDone < need1) __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
+        }
+        trDone = upDone >= need2;
         PHASE_STAMP(4);  // poll the row above
         if (lane < 17) {
           // dword j of the window: Y (lanes 0..7) covers x = 4j-4..4j-1, Cb/Cr (lanes 8..11 / 12..15) likewise with 8-pixel macroblocks
@@ -840,7 +848,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
       }
       WAVE_SYNC();
       // Intra4x4 / Intra8x8 with a top-right macroblock: make sure its bottom line is there before the luma blocks
-      const bool lateTR = (kind == 0 || kind == 1) && mbC && !trDone;
+      const bool lateTR = (kind == 0 || (HAS_I8 && kind == 1)) && mbC && !trDone;
       wOff += lane < 8 ? 16u : 8u;
       const uint8_t* up = ws->up;
       PHASE_STAMP(5);  // neighbour window fetch
@@ -955,15 +963,17 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 #ifdef DRYV_SKIP_LUMA
       } else if (kind == 8) {
 #else
-      } else if (kind == 0 || kind == 1) {
+      } else if (kind == 0 || (HAS_I8 && kind == 1)) {
 #endif
         // mode grid: lanes 0..15 = by*4+bx (raster)
         const int mbx = lane & 3, mby = (lane >> 2) & 3;
         if (lateTR) {
           // fetch x = 16..23 of the row above (window dwords 5 and 6: the bottom line of macroblock mx+1) now
           if (upLds) {
-            while (__hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need2)
-              __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
+            while (upDone < need2) {
+              upDone = (unsigned)rfl((int)__hip_atomic_load(&bs->prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+              if (upDone < need2) __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
+            }
             if (lane == 5 || lane == 6)
               ((unsigned*)ws->up)[lane] = *(const unsigned*)&bs->ringY[wave - 1][((mx + 1) & (RING_K - 1)) * 16 + (lane - 5) * 4];
           } else {
@@ -983,7 +993,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         const unsigned upM = mbB ? *(const unsigned*)&up[UPM] : 0x02020202u;
         const int Tb = (int)((upM >> (8 * mbx)) & 0xff);  // meaningful on lanes with mby == 0
         const int Lb = dpp<ROW_SHL(3)>(Mprev, Mprev);     // meaningful on lanes with mbx == 0: left MB's column 3
-        if (kind == 0) {
+        if (!HAS_I8 || kind == 0) {
           if (mbA && mbC) Mcur = i4_macroblock<true>(ws, ldsBase + LT_T4E, rl, lane, Tb, Lb, prevFlags, remBits, true, true, true);
           else Mcur = i4_macroblock<false>(ws, ldsBase + LT_T4E, rl, lane, Tb, Lb, prevFlags, remBits, mbA, mbB, mbC);
         } else {
@@ -1064,8 +1074,10 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         // ring entry mx replaces entry mx-RING_K, which the row below needs until it has copied the window of
         // macroblock mx-RING_K+1
 #ifndef DRYV_NO_WAIT
-        while ((int)__hip_atomic_load(&bs->cons[wave + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < mx - RING_K + 2)
-          __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
+        while (consKnown < mx - RING_K + 2) {  // (cached like upDone)
+          consKnown = rfl((int)__hip_atomic_load(&bs->cons[wave + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (consKnown < mx - RING_K + 2) __builtin_amdgcn_s_sleep(DRYV_POLL_SLEEP);
+        }
 #endif
       }
       const bool lastMb = mx + 1 == W;
