@@ -787,7 +787,9 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         if (lane < 32) {
           const int bx = b8 & 1, by = b8 >> 1;
 #pragma unroll
-          for (int k = 0; k < 8; k++) ws->resB[(8 * by + k) * 16 + 8 * bx + i] = (int16_t)((oo[k] + 32) >> 6);
+          // (clamped: clip255(pred + r) only sees r through [-255, 255], so 16 bits carry any int32 residual exactly)
+          for (int k = 0; k < 8; k++)
+            ws->resB[(8 * by + k) * 16 + 8 * bx + i] = (int16_t)min(max((oo[k] + 32) >> 6, -512), 511);
         }
       }
       WAVE_SYNC();

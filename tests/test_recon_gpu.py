@@ -116,6 +116,22 @@ def test_fuzz_geometries_and_configs(recon_ctx):
                 kk: vv for kk, vv in fkw.items() if not hasattr(vv, "shape")}, e))
 
 
+def test_full_int16_coefficient_range(recon_ctx):
+    """The FFI carries int16 coefficients; the kernel computes in int32 where the reference uses 64-bit isize.
+    With flat lists and qp <= 24 every intermediate of |c| <= 32767 fits 32 bits, so the
+    results must still be identical -- including residuals far outside [-255, 255], which the Intra4x4 path
+    carries clamped."""
+    rng = np.random.default_rng(9)
+    fp = abi.make_frame_params(9, 7, transform_8x8=True)
+    frames = 3
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3, coded=1.0, p0=0.9, decay4=0.97, decay8=0.99,
+                                              qp=(0, 24)), 61, 0, frames)
+    scale = rng.choice([1, 40, 700, 6000], size=(co.shape[0], 1))
+    co = np.clip(co.astype(np.int64) * scale, -32768, 32767).astype(np.int16)
+    assert np.abs(co.astype(np.int32)).max() == 32768 or np.abs(co.astype(np.int32)).max() >= 32767
+    assert_parity(recon_ctx, fp, frames, mbs, co)
+
+
 def test_nonflat_scaling_lists(recon_ctx):
     """Non-flat matrices: chroma re-uses the luma (list 0) LevelScale tables — quirk Q3."""
     rng = np.random.default_rng(5)
