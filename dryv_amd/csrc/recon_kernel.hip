@@ -1,40 +1,43 @@
 // recon_kernel.hip — gfx950 (CDNA4 / MI355X) macroblock reconstruction for dryv's AVC intra path.
 //
 // Work decomposition
-//   * One 64-lane wavefront processes one macroblock ROW of one frame, left to right. Rows of a frame advance
-//     as a 2:1 diagonal: row r may process macroblock x once row r-1 has finished macroblock x+1 (top-right
-//     neighbour C; reference slice/macroblock.rs:455-456, slice/mod.rs:593-598).
-//   * The unit handed out by the global queue is a BAND: 4 consecutive rows of one frame, one per wave of a
-//     256-thread workgroup. Inside a band, rows hand off through a 16-macroblock LDS ring (bottom pixel line +
-//     bottom-row prediction modes) with two-way LDS progress counters: a hand-off costs ~100 cycles, so the four
-//     rows run at the minimum legal lag of 2 macroblocks.
+//   * One 64-lane wavefront processes one macroblock ROW of one frame, left to right. Row r may start macroblock x
+//     once row r-1 has finished macroblock x (neighbours B and D) and must see macroblock x+1 finished (neighbour
+//     C; reference slice/macroblock.rs:455-456, slice/mod.rs:593-598) only before the one Intra4x4 / Intra8x8
+//     block that reads its samples.
+//   * The unit handed out by the global queue is a BAND: 4 consecutive rows of one frame, one per wave. A
+//     512-thread workgroup runs two independent bands that share nothing but the constant tables; the waves of a
+//     band synchronise through LDS counters, never through a workgroup barrier. Inside a band, rows hand off
+//     through an 8-macroblock LDS ring (bottom pixel line + bottom-row prediction modes) with two-way progress
+//     counters (cached in SGPRs: a poll that is already satisfied costs nothing).
 //   * Between bands the hand-off goes through L2 (MI355X_MICROARCH.md, "valid forms"): the last row of a band
 //     stores its bottom pixel line and modes write-through (sc1), drains vmcnt, then stores its progress counter
 //     (sc1); wave 0 of the band below polls that counter and reads the 25+9+9 neighbour samples with sc1 loads
-//     only (they bypass the CU's L1, so no acquire/invalidate is needed). Bands are claimed in the order (band 0
-//     of every frame, band 1 of every frame, ...): the band a task depends on was always claimed earlier, so its
-//     owner is running or done and a waiting wave can never deadlock; and it is ~4 x (frames x W / waves)
-//     macroblocks ahead, so this slow hand-off practically never blocks. Any workgroup can take any band:
-//     300 independent frames spread evenly over 256 CUs.
+//     only (they bypass the CU's L1, so no acquire/invalidate is needed). Every band comes off ONE queue in the
+//     order (band 0 of every frame, band 1 of every frame, ...): the band a task depends on has a smaller number,
+//     so it was claimed earlier by a workgroup that is running or done -- no deadlock however few workgroups are
+//     resident -- and it is ~4 x (frames x W / waves) macroblocks ahead, so this slow hand-off practically never
+//     blocks. Any band slot can take any band: 300 independent frames spread evenly over 256 CUs.
 //   * HBM traffic per macroblock: 768 B of coefficients in (one global->LDS DMA of 48 x 16 B, issued a
-//     macroblock ahead), a 16 B record, 384 B of pixels out (one dword per lane); per band boundary row 4 B of
-//     modes and a 68 B neighbour window re-read through L2.
+//     macroblock ahead), a 16 B record, 384 B of pixels out, staged in LDS and stored as whole 32-byte row
+//     segments (luma every 2nd, chroma every 4th macroblock); per band boundary row 4 B of modes and a 68 B
+//     neighbour window re-read through L2.
 //
-// Inside a macroblock (registers / DPP unless noted)
-//   * residual: 4 lanes per 4x4 block; lane = one row of coefficients (inverse zig-zag is a 4-way LDS
-//     gather), dequantise, row butterfly in-lane, DPP quad transpose, column butterfly in-lane.
-//   * Intra16x16 and chroma: predicted straight from the neighbour window / left-edge bytes, clip-added,
-//     packed 4 pixels per dword, byte-transposed across the quad (v_perm_b32) and stored.
-//   * Intra4x4: prediction modes by a 7-sweep DPP relaxation over the 4x4 block grid; pixels by a
-//     statically unrolled 10-step 2:1 block wavefront, 16 lanes per block: one LDS byte gather of the 13
-//     reference samples E, the 3-tap / 2-tap filtered lines F, G by DPP row shifts, then ONE ds_bpermute
-//     per block picks each pixel's sample from E/F/G through a mode table (every directional mode of
-//     8.3.1.2 reads exactly one of E[i], F[i], G[i]).
-//   * Intra8x8: same idea on 64 lanes (one pixel per lane), incl. the reference's filter quirk Q1.
+// Inside a macroblock
+//   * residual: 4 lanes per 4x4 block; lane = one row of coefficients (inverse zig-zag is a 4-way LDS gather),
+//     table dequantisation, row butterfly in-lane, 4x4 transpose through swizzled LDS slots, column butterfly.
+//   * Intra16x16 and chroma: predicted in registers from the neighbour window / left-edge bytes, clip-added,
+//     packed 4 pixels per dword, byte-transposed across the quad (v_perm_b32).
+//   * Intra4x4: prediction modes by a 7-sweep DPP relaxation over the 4x4 block grid; pixels by a statically
+//     unrolled 10-step 2:1 block wavefront, 16 lanes per block: every pixel is (E[p] + 2E[q] + E[r] + 2) >> 2 of
+//     three reference samples whose tile offsets come from a per-(mode, pixel) table -- three LDS byte reads, no
+//     cross-lane traffic (see I4Lane).
+//   * Intra8x8: 64 lanes (one pixel per lane); reference samples on lanes 0..24, the reference's filter (incl.
+//     quirk Q1) by lane shuffles, one ds_bpermute picks E/F/G per pixel through a mode table.
 //
-// Bit-exact with the reference's Rust CPU path (quirks Q1-Q5 of SURVEY.md §8a' included). Arithmetic is
-// int32 (reference: 64-bit isize): exact whenever every intermediate fits 32 bits, which holds for any
-// conformant 8-bit stream and for |level| <= 2047 with flat scaling lists at every QP.
+// Bit-exact with the reference's Rust CPU path (quirks Q1-Q5 of SURVEY.md 8a' included). Arithmetic is int32
+// (reference: 64-bit isize): exact whenever every intermediate fits 32 bits -- any conformant 8-bit stream,
+// |level| <= 2047 with flat scaling lists at every QP, the full int16 range at qp <= 24.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
