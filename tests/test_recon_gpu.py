@@ -275,3 +275,23 @@ def test_oversubscribed_grid_completes(tmp_path):
         env = dict(os.environ, DRYV_RECON_GRID=grid)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
         assert r.returncode == 0 and "ok" in r.stdout, (grid, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_two_contexts_in_flight(recon_ctx):
+    """Two contexts (own stream, staging buffers and workspace each) with submits in flight at the same time."""
+    from dryv_amd import ReconContext
+    other = ReconContext(0)
+    try:
+        fpa = abi.make_frame_params(40, 23, transform_8x8=True)
+        fpb = abi.make_frame_params(33, 18)
+        ma, ca = synth.generate(fpa, synth.config(i4x4=0.4, i8x8=0.3), 901, 0, 6)
+        mb_, cb = synth.generate(fpb, synth.config(i4x4=0.7, i8x8=0.0), 902, 0, 9)
+        for _ in range(3):
+            recon_ctx.submit(fpa, 6, ma, ca)
+            other.submit(fpb, 9, mb_, cb)
+            ga = recon_ctx.wait()
+            gb = other.wait()
+        assert np.array_equal(ga, oracle.reconstruct(fpa, 6, ma, ca)[1])
+        assert np.array_equal(gb, oracle.reconstruct(fpb, 9, mb_, cb)[1])
+    finally:
+        other.close()
