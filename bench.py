@@ -66,18 +66,26 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # One rank per GPU. (DRYV_BENCH_BACKEND=gloo is a rehearsal hook for boxes with fewer GPUs than ranks: the ranks
+    # then share devices and the control plane runs over gloo on the host; the product path is RCCL.)
+    backend = os.environ.get("DRYV_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    ctrl = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)   # backend "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)   # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     # ---- control plane: rank 0 decides, everyone receives (RCCL broadcast) ----------------------
     cid, w, h, frames, t8, kw = synth.WORKLOADS[args.workload]
     per_gpu = args.frames_per_gpu or frames
     fp = dryv_amd.make_frame_params(w, h, transform_8x8=t8)
     table = shard.partition_frames(per_gpu * world, world)
-    fp, table = shard.broadcast_control(fp, table, device, rank, world)
+    fp, table = shard.broadcast_control(fp, table, ctrl, rank, world)
     first, n_frames = table[rank]
     per = fp.pic_width_in_mbs * fp.pic_height_in_mbs
     n_mbs = n_frames * per
@@ -90,7 +98,7 @@ def main():
     d_out = torch.zeros(n_mbs * 384, dtype=torch.uint8, device=device)
     torch.cuda.synchronize()
 
-    ctx = dryv_amd.ReconContext(local_rank)
+    ctx = dryv_amd.ReconContext(dev_index)
 
     def step():
         ctx.submit_device(fp, n_frames, d_mbs.data_ptr(), d_coeffs.data_ptr(), d_out.data_ptr())
@@ -111,12 +119,12 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=ctrl)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    reports = shard.gather_reports(n_frames, n_mbs, shard.plane_checksum(d_out), device, world)
+    reports = shard.gather_reports(n_frames, n_mbs, shard.plane_checksum(d_out), ctrl, world)
     total_mbs = sum(r[1] for r in reports)
 
     if rank == 0:
