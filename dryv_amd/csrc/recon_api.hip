@@ -35,6 +35,7 @@ struct dryv_recon_ctx {
   size_t cap_work = 0;
   int num_cus = 256;
   int grid_override = 0;
+  bool use_df = false;  // dual-frame kernel (DRYV_RECON_DF=1)
   std::string last_error;
 };
 
@@ -171,15 +172,18 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   // Persistent grid: 32 waves per CU (8 per SIMD at 64 VGPRs); each band slot of a workgroup keeps claiming 4-row
   // bands until none are left, so a smaller grid is merely slower and never incorrect.
   const int bpb = dryv::recon_bands_per_block();
-  const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
-  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::recon_blocks_per_cu();
+  const bool df = ctx->use_df;
+  const long long total_bands = df ? dryv::recon_task_count_df(P.H, P.n_frames) : (long long)P.n_frames * ((P.H + 3) / 4);
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override
+                                          : (long long)ctx->num_cus * (df ? 2 : dryv::recon_blocks_per_cu());
   if (grid > (total_bands + bpb - 1) / bpb) grid = (total_bands + bpb - 1) / bpb;
   if (grid < 1) grid = 1;
   e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
   e = hipEventRecord(ctx->ev_start, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
+  e = df ? dryv::recon_launch_df(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream)
+         : dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "recon_kernel launch");
   e = hipEventRecord(ctx->ev_stop, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
@@ -225,6 +229,7 @@ int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
       ctx->num_cus = prop.multiProcessorCount;
   }
   if (const char* s = getenv("DRYV_RECON_GRID")) ctx->grid_override = atoi(s);
+  if (const char* s = getenv("DRYV_RECON_DF")) ctx->use_df = atoi(s) != 0;
   *out = ctx;
   return DRYV_OK;
 }
