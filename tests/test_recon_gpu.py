@@ -295,3 +295,29 @@ def test_two_contexts_in_flight(recon_ctx):
         assert np.array_equal(gb, oracle.reconstruct(fpb, 9, mb_, cb)[1])
     finally:
         other.close()
+
+
+def test_dual_frame_variant_parity():
+    """The experimental dual-frame kernel (DRYV_RECON_DF=1: each wave works on the same row of two frames; off by
+    default) must stay bit-exact too: odd and even frame counts, every kind, band boundaries."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import oracle\n"
+        "from dryv_amd import abi, synth, ReconContext\n"
+        "ctx = ReconContext(0)\n"
+        "rng = np.random.default_rng(5)\n"
+        "for k in range(16):\n"
+        "    W, H, frames = int(rng.integers(1, 40)), int(rng.integers(1, 14)), int(rng.integers(1, 6))\n"
+        "    i8 = float(rng.choice([0.0, 0.3]))\n"
+        "    fp = abi.make_frame_params(W, H, transform_8x8=i8 > 0)\n"
+        "    mbs, co = synth.generate(fp, synth.config(i4x4=0.5, i8x8=i8, legal_modes_only=bool(k & 1)), 500 + k, k, frames)\n"
+        "    st, want = oracle.reconstruct(fp, frames, mbs, co)\n"
+        "    got = ctx.reconstruct(fp, frames, mbs, co)\n"
+        "    assert st == 0 and np.array_equal(got, want), (k, W, H, frames)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, DRYV_RECON_DF="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
