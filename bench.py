@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=None)
     ap.add_argument("--cpu-sample-frames", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-ms", type=float, default=40.0, help="untimed device pre-roll before the warm-up steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,6 +121,12 @@ def main():
     def step():
         ctx.submit_device(fp, n_frames, d_mbs.data_ptr(), d_coeffs.data_ptr(), d_out.data_ptr())
 
+    # Device pre-roll (untimed, not part of W): the GPU leaves its idle clocks only after some tens of milliseconds
+    # of work; without it the first timed steps of a short run are measured at a lower clock than the rest.
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+        step()
+        ctx.sync()
     for _ in range(args.warmup):
         step()
         ctx.sync()
