@@ -25,9 +25,20 @@ def _stale(target, sources):
 
 
 def _run(cmd):
+    """Runs a compiler command whose output file follows "-o". The output is written under a private name and moved
+    into place atomically: several ranks of one job may find the same library stale at the same time."""
+    cmd = list(cmd)
+    i = cmd.index("-o") + 1
+    final = cmd[i]
+    cmd[i] = "%s.tmp%d" % (final, os.getpid())
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
+        try:
+            os.unlink(cmd[i])
+        except OSError:
+            pass
         raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    os.replace(cmd[i], final)
     return r.stdout
 
 
