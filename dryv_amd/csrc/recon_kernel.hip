@@ -684,8 +684,6 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
     const bool toGlobal = wave + 1 == BAND && r + 1 < H;
     const size_t mbBase = (size_t)f * W * H + (size_t)r * W;
     uint8_t* planeY = yuv + (size_t)f * frameBytes;
-    uint8_t* planeCb = planeY + (size_t)W * H * 256;
-    uint8_t* planeCr = planeCb + (size_t)W * H * 64;
     unsigned* myProg = rowProg + (size_t)f * H + r;
     const unsigned* upProg = myProg - 1;
     unsigned* myModes = rowModes + mbBase;
