@@ -1,0 +1,817 @@
+// band_kernel.h — macroblock reconstruction, one wavefront per BAND of four macroblock rows (gfx950).
+//
+// Decomposition
+//   * The unit of work is a band: 4 consecutive macroblock rows of one frame. ONE 64-lane wave owns it; lanes
+//     16g..16g+15 belong to row g of the band. The rows advance in lockstep as a 2:1 diagonal: at step s row g
+//     works on macroblock x = s - 2g, so neighbours A, B, C, D of every macroblock (slice/mod.rs:576-613) were
+//     finished by the same wave one or two steps earlier -- no synchronisation inside a band at all.
+//   * Bands come off one queue in band-major order (band 0 of every frame, band 1 of every frame, ...): a band's
+//     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running or done, so
+//     there is no deadlock at any residency. 300 frames x 17 bands = 5100 waves fit the chip at once (5 per SIMD).
+//   * Between bands the hand-off goes through L2 (MI355X_MICROARCH.md "valid forms", sc1 stores + drained flag,
+//     sc1 loads): the band's last row stores its bottom pixel lines and bottom-row modes write-through, and two
+//     steps later -- when a counted s_waitcnt has shown those stores complete -- publishes its progress word. The
+//     band below polls that word one step ahead and fetches one macroblock's lines per step into its ring.
+//
+// Inside a step (4 macroblocks)
+//   * residual: ONE LANE PER 4x4 BLOCK. The lane loads its block's 16 coefficients (32 contiguous bytes of the
+//     reference's list order) straight into registers, so the inverse zig-zag is register renaming, both butterfly
+//     passes are in-lane, and no transpose or LDS traffic exists. Luma: 64 lanes = 4 MB x 16 blocks; chroma: 32
+//     lanes = 4 MB x 2 planes x 4 blocks. Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP.
+//     int32 arithmetic with a per-qp coefficient bound (KParams::thr4); a wave whose pass exceeds it re-runs the
+//     pass in int64 (reference: isize), so the result is the reference's for every int16 input.
+//   * Intra16x16 and chroma prediction stay in the lane-per-block layout (residuals never leave registers): V, H
+//     and DC are one v_perm_b32 byte-select per pixel pair, plane is packed 16-bit arithmetic.
+//   * Intra4x4: prediction modes by the 7-sweep DPP relaxation over the block grid (one DPP row per macroblock),
+//     pixels by a 10-step 2:1 block wavefront with 8 lanes per block (2 pixels each): every pixel is
+//     (E[p] + 2E[q] + E[r] + 2) >> 2 of three samples whose tile offsets come from a per-(mode, pixel) table.
+//   * pixels are staged in LDS two macroblocks wide and stored as whole 32-byte row segments every other step.
+//
+// Written against wave.h: the same source runs on the GPU and, lane by lane, in the CPU emulator of tests/emu.
+#pragma once
+#include "../../include/dryv_recon.h"
+#include "kparams.h"
+#include "wave.h"
+
+namespace dryv {
+namespace band {
+
+// ---- per-workgroup constant tables in LDS (byte offsets) ----------------------------------------------------
+constexpr int T_LS4Z = 0;     // u16 [6][16]    LevelScale4x4 in list order
+constexpr int T_QPC = 192;    // u8  [2][52]    QP'c for Cb / Cr as a function of QPY (transform.rs:194-216)
+constexpr int T_THR4 = 304;   // u16 [52]
+constexpr int T_THR8 = 408;   // u16 [52]
+constexpr int T_T4E = 512;    // u32 [12][8][2] Intra4x4 entries [mode][pixel pair][pixel]
+constexpr int T_END = 1280;
+constexpr int T_LS8 = 1280;   // u16 [6][64]    (HAS_I8 only)
+constexpr int T_END_I8 = 2048;
+
+// ---- per-wave scratch in LDS (byte offsets from the wave's base) ---------------------------------------------
+constexpr int TILE_STRIDE = 40;
+constexpr int TILE_BYTES = 704;  // 17 rows x 40 + 8 (row y = -1 of slot 1 reaches 8 bytes into row y = 0), 64-aligned
+constexpr int S_RES = 0;         // i16 [4][16 blk][16]  luma residual of Intra4x4 macroblocks, [blkIdx][y][x]
+constexpr int S_TILE = 2048;     // u8  [4][TILE_BYTES]  luma: row j = y + 1, column 8 + 16 * (x & 1) + xr
+constexpr int S_STC = S_TILE + 4 * TILE_BYTES;  // u8 [4][2][8][16] chroma staging, two macroblocks wide
+constexpr int S_RING = S_STC + 1024;            // [4][4][40] bottom lines of the row above: Y[16] Cb[8] Cr[8] modes
+constexpr int RING_ROW = 160, RING_ENT = 40;
+constexpr int S_LEFTY = S_RING + 640;           // u8 [4][16] column 15 of the macroblock to the left
+constexpr int S_LEFTC = S_LEFTY + 64;           // u8 [4][2][8]
+constexpr int S_MSEQ = S_LEFTC + 64;            // u8 [4][2][12] Intra4x4 table row per chain step and block half
+constexpr int S_BYTES = 6784;                   // (64-byte multiple)
+static_assert(S_MSEQ + 96 <= S_BYTES, "scratch layout");
+
+constexpr int WAVES_PER_WG = 5;
+
+struct Args {
+  const dryv_mb_desc* mbs;
+  const int16_t* coeffs;
+  uint8_t* yuv;
+  unsigned* status;
+  unsigned* bandProg;   // [frame][band]: macroblocks of the band's last row whose bottom lines are visible
+  unsigned* rowModes;   // [mb]: bottom-row Intra4x4/8x8 modes (only rows that end a band are written)
+  unsigned* taskCounter;
+};
+
+// zig-zag (frame/mod.rs:185-209): list index of matrix element (row, col)
+#define ZZ4IDX(r, c) ((int)((0xFEA9DB83C7426510ull >> (4 * ((r) * 4 + (c)))) & 15ull))
+// Intra4x4 block wavefront: step T runs the blocks with bx + 2*by == T (at most two)
+constexpr int stepByLo(int t) { return t < 2 ? 0 : (t - 2) >> 1; }
+constexpr int stepByHi(int t) { return (t >> 1) < 3 ? (t >> 1) : 3; }
+constexpr int zidx(int bx, int by) { return 8 * (by >> 1) + 4 * (bx >> 1) + 2 * (by & 1) + (bx & 1); }
+
+// Builds the per-workgroup tables. Called by every thread of the workgroup (tid / nthreads), followed by a barrier.
+WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool hasI8) {
+  for (int k = tid; k < 96; k += nthreads) wv::lds_st16(ldsBase + T_LS4Z + 2 * k, P.ls4z[k]);
+  for (int k = tid; k < 104; k += nthreads) {
+    // 8.5.8: qPI = Clip3(0, 51, QPY + offset); QPc = qPI < 30 ? qPI : table 8-15
+    const int qpi = min(max((k % 52) + (k < 52 ? P.cqo_cb : P.cqo_cr), 0), 51);
+    const int d = qpi - 30;
+    const int delta = d < 0 ? 0 : d < 16 ? (int)((0x7765544332221111ull >> (4 * d)) & 15ull) : (int)((0xCBA998u >> (4 * (d - 16))) & 15u);
+    wv::lds_st8(ldsBase + T_QPC + k, (unsigned)(qpi - delta));
+  }
+  for (int k = tid; k < 52; k += nthreads) {
+    wv::lds_st16(ldsBase + T_THR4 + 2 * k, P.thr4[k]);
+    wv::lds_st16(ldsBase + T_THR8 + 2 * k, P.thr8[k]);
+  }
+  for (int k = tid; k < 192; k += nthreads) {
+    // entry of (table row m, pixel pair p, pixel e): shift | DC flag << 5 | three tile offsets relative to
+    // (block origin - one row - one column) << 8/16/24. P.t4 names a sample by its index j on the line
+    // E = [L3 L2 L1 L0 | corner | T0..T7] and says whether the pixel is E[j], the 3-tap or the 2-tap value there.
+    // Rows 0..8 = the modes, 9 = zero prediction (quirk Q4), 10 / 11 = modes 3 / 7 without a top-right block.
+    const int m = k >> 4, p = (k >> 1) & 7, e = k & 1;
+    const int x = 2 * (p & 1) + e, y = p >> 1;
+    const int mode = m < 10 ? m : (m == 10 ? 3 : 7), jmax = m < 10 ? 12 : 8;
+    unsigned v;
+    if (mode == 9) v = 31u;
+    else if (mode == 2) v = 31u | 32u;
+    else {
+      const int en = P.t4[mode * 16 + y * 4 + x], j = en & 31, sel = en >> 5;
+      const int ja = sel == 1 ? j - 1 : j, jb = sel == 2 ? j + 1 : j, jc = sel == 1 ? j + 1 : j;
+      const int a = min(max(ja, 0), jmax), bq = min(max(jb, 0), jmax), c = min(max(jc, 0), jmax);
+      const unsigned pa = (unsigned)(a <= 3 ? (4 - a) * TILE_STRIDE : a - 4);
+      const unsigned pb = (unsigned)(bq <= 3 ? (4 - bq) * TILE_STRIDE : bq - 4);
+      const unsigned pc = (unsigned)(c <= 3 ? (4 - c) * TILE_STRIDE : c - 4);
+      v = 2u | (pa << 8) | (pb << 16) | (pc << 24);
+    }
+    wv::lds_st32(ldsBase + T_T4E + 4 * k, v);
+  }
+  if (hasI8)
+    for (int k = tid; k < 384; k += nthreads) wv::lds_st16(ldsBase + T_LS8 + 2 * k, P.ls8[k]);
+}
+
+// ---- 4x4 residual of one block, all in this lane (transform.rs:116-191, 8.5.12) --------------------------------
+// c0/c1: the block's 16 list entries as packed int16 pairs; ls: LevelScale of qp%6 in list order, same packing.
+// d = ((c * LS) << shl + rnd) >> shr  ==  transform.rs:147-152 with shl = max(qp/6-4,0), shr = max(4-qp/6,0),
+// rnd = 2^(3-qp/6) below qp 24. useDc: element (0,0) arrives already scaled (Intra16x16 / chroma, :145-146).
+// Out: residual [y][x] as 8 saturated int16 pairs (clip255(pred + r) cannot tell r from its clamp to int16).
+template <typename T>
+WV void idct4x4(const u32x4 c0, const u32x4 c1, const u32x4 l0, const u32x4 l1, int shl, int rnd, int shr, bool useDc,
+                T dcVal, unsigned out[8]) {
+  const unsigned cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const unsigned lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+  T d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int c = (k & 1) ? ((int)cw[k >> 1] >> 16) : (int)(int16_t)cw[k >> 1];
+    const int l = (k & 1) ? (int)(lw[k >> 1] >> 16) : (int)(lw[k >> 1] & 0xffffu);
+    d[k] = ((((T)(c * l)) * ((T)1 << shl)) + (T)rnd) >> shr;   // |c * l| < 2^15 * 7395 fits int32
+  }
+  if (useDc) d[0] = dcVal;
+  T f[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {  // row butterflies (transform.rs:159-169)
+    const T m0 = d[ZZ4IDX(r, 0)], m1 = d[ZZ4IDX(r, 1)], m2 = d[ZZ4IDX(r, 2)], m3 = d[ZZ4IDX(r, 3)];
+    const T e0 = m0 + m2, e1 = m0 - m2, e2 = (m1 >> 1) - m3, e3 = m1 + (m3 >> 1);
+    f[r][0] = e0 + e3;
+    f[r][1] = e1 + e2;
+    f[r][2] = e1 - e2;
+    f[r][3] = e0 - e3;
+  }
+  T h[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {  // column butterflies (:171-181), rounding (:183-187)
+    const T g0 = f[0][c] + f[2][c], g1 = f[0][c] - f[2][c], g2 = (f[1][c] >> 1) - f[3][c], g3 = f[1][c] + (f[3][c] >> 1);
+    h[0][c] = (g0 + g3 + 32) >> 6;
+    h[1][c] = (g1 + g2 + 32) >> 6;
+    h[2][c] = (g1 - g2 + 32) >> 6;
+    h[3][c] = (g0 - g3 + 32) >> 6;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (sizeof(T) == 4) {
+      out[2 * r] = wv::cvt_pk_i16((int)h[r][0], (int)h[r][1]);
+      out[2 * r + 1] = wv::cvt_pk_i16((int)h[r][2], (int)h[r][3]);
+    } else {
+      const T lo = (T)-32768, hi = (T)32767;
+      const int a0 = (int)min(max(h[r][0], lo), hi), a1 = (int)min(max(h[r][1], lo), hi);
+      const int a2 = (int)min(max(h[r][2], lo), hi), a3 = (int)min(max(h[r][3], lo), hi);
+      out[2 * r] = ((unsigned)a0 & 0xffffu) | ((unsigned)a1 << 16);
+      out[2 * r + 1] = ((unsigned)a2 & 0xffffu) | ((unsigned)a3 << 16);
+    }
+  }
+}
+
+// The same transform in 64-bit arithmetic (the reference's isize), for blocks whose intermediates may not fit int32.
+// Taken by a whole wave when any of its lanes needs it; never for a conformant stream. Written for few live
+// registers rather than speed: the column butterflies are done one column at a time and the row pass is
+// recomputed for each, so only a handful of wide values are ever live besides the packed inputs.
+WV void idct4x4_wide(const u32x4 c0, const u32x4 c1, int lsAddr, int shl, int rnd, int shr, bool useDc, long long dcVal,
+                     unsigned out[8]) {
+  typedef long long T;
+  unsigned cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  auto dq = [&](int k) -> T {
+    const int c = (k & 1) ? ((int)cw[k >> 1] >> 16) : (int)(int16_t)cw[k >> 1];
+    const int l = (int)wv::lds_u16(lsAddr + 2 * k);  // (re-read per use: registers matter here, time does not)
+    const T d = (T)(((unsigned long long)(T)(c * l) << shl) + (unsigned long long)rnd) >> shr;
+    return (k == 0 && useDc) ? dcVal : d;
+  };
+  int hold[4] = {0, 0, 0, 0};
+#pragma clang loop unroll(disable)
+  for (int col = 0; col < 4; col++) {
+    T fa[4];  // column `col` of the row-pass output
+#pragma unroll
+    for (int k = 0; k < 8; k++) cw[k] = (unsigned)wv::opaque((int)cw[k]);  // (keeps the dequantisation inside the loop)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const T m0 = dq(ZZ4IDX(r, 0)), m1 = dq(ZZ4IDX(r, 1)), m2 = dq(ZZ4IDX(r, 2)), m3 = dq(ZZ4IDX(r, 3));
+      const T e0 = m0 + m2, e1 = m0 - m2, e2 = (m1 >> 1) - m3, e3 = m1 + (m3 >> 1);
+      fa[r] = col == 0 ? e0 + e3 : col == 1 ? e1 + e2 : col == 2 ? e1 - e2 : e0 - e3;
+    }
+    const T g0 = fa[0] + fa[2], g1 = fa[0] - fa[2], g2 = (fa[1] >> 1) - fa[3], g3 = fa[1] + (fa[3] >> 1);
+    const T lo = (T)-32768, hi = (T)32767;
+    const int h0 = (int)min(max((g0 + g3 + 32) >> 6, lo), hi), h1 = (int)min(max((g1 + g2 + 32) >> 6, lo), hi);
+    const int h2 = (int)min(max((g1 - g2 + 32) >> 6, lo), hi), h3 = (int)min(max((g0 - g3 + 32) >> 6, lo), hi);
+    if ((col & 1) == 0) {
+      hold[0] = h0; hold[1] = h1; hold[2] = h2; hold[3] = h3;
+    } else {
+      const unsigned o0 = ((unsigned)hold[0] & 0xffffu) | ((unsigned)h0 << 16), o1 = ((unsigned)hold[1] & 0xffffu) | ((unsigned)h1 << 16);
+      const unsigned o2 = ((unsigned)hold[2] & 0xffffu) | ((unsigned)h2 << 16), o3 = ((unsigned)hold[3] & 0xffffu) | ((unsigned)h3 << 16);
+      if (col == 1) { out[0] = o0; out[2] = o1; out[4] = o2; out[6] = o3; }
+      else { out[1] = o0; out[3] = o1; out[5] = o2; out[7] = o3; }
+    }
+  }
+}
+
+// largest |c| over the block's entries (entry 0 excluded when it is not a coefficient of this block)
+WV int max_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
+  const unsigned cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int c = (k & 1) ? ((int)cw[k >> 1] >> 16) : (int)(int16_t)cw[k >> 1];
+    if (k == 0 && skip0) c = 0;
+    m = max(m, c < 0 ? -c : c);
+  }
+  return m;
+}
+
+// One pass of lane-per-block residuals. big = this lane's block may overflow int32 -> the whole wave takes the
+// 64-bit instantiation (wave-uniform branch; never taken for conformant streams).
+WV void residual_pass(const u32x4 c0, const u32x4 c1, int lsAddr, int qp, bool useDc, long long dcVal, int thr,
+                      unsigned out[8]) {
+  const int qd = (qp * 43) >> 8;
+  const int shl = max(qd - 4, 0), shr = max(4 - qd, 0), rnd = qd < 4 ? (1 << (3 - qd)) : 0;
+  bool big = false;
+  if (wv::any(thr != 0xFFFF)) big = thr != 0xFFFF && max_abs16(c0, c1, useDc) > thr;
+  if (useDc && (dcVal > (1ll << 26) || dcVal < -(1ll << 26))) big = true;
+  if (wv::any(big)) idct4x4_wide(c0, c1, lsAddr, shl, rnd, shr, useDc, dcVal, out);
+  else {
+    const u32x4 l0 = wv::lds_u128(lsAddr), l1 = wv::lds_u128(lsAddr + 16);
+    idct4x4<int>(c0, c1, l0, l1, shl, rnd, shr, useDc, (int)dcVal, out);
+  }
+}
+
+// lane i ^ 4 and i ^ 8 inside a 16-lane DPP row
+WV int xor4(int v, bool bit2) {
+  const int a = wv::dpp<DPP_ROW_ROR(12)>(v, v), b = wv::dpp<DPP_ROW_ROR(4)>(v, v);
+  return bit2 ? b : a;
+}
+WV int xor8(int v) { return wv::dpp<DPP_ROW_ROR(8)>(v, v); }
+WV int xor1(int v) { return wv::dpp<DPP_QUAD(1, 0, 3, 2)>(v, v); }
+WV int xor2(int v) { return wv::dpp<DPP_QUAD(2, 3, 0, 1)>(v, v); }
+
+// One reconstructed row of 4 pixels: prediction as two u16 pairs, residual as two i16 pairs
+WV unsigned recon_row(unsigned p01, unsigned p23, unsigned r01, unsigned r23) {
+  const unsigned a = wv::sat_pk_u8(wv::pk_add_sat(p01, r01)), b = wv::sat_pk_u8(wv::pk_add_sat(p23, r23));
+  return (a & 0xffffu) | (b << 16);
+}
+
+// ---- the kernel body: one wave, any number of band tasks -----------------------------------------------------
+template <bool HAS_I8>
+WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int ws) {
+  const int lane0 = wv::lane_id();
+  const int W = P.W, H = P.H, nF = P.n_frames;
+  const int nBands = (H + 3) >> 2;
+  const unsigned totalTasks = (unsigned)nF * (unsigned)nBands;
+  const int pitchY = W * 16, pitchC = W * 8;
+  const size_t frameBytes = (size_t)W * H * 384;
+  const unsigned offCb = (unsigned)W * H * 256u, offCr = offCb + (unsigned)W * H * 64u;
+
+  for (;;) {
+    unsigned tsk = 0;
+    if (lane0 == 0) tsk = wv::atomic_inc_task(A.taskCounter);
+    const unsigned task = (unsigned)wv::rfl((int)tsk);
+    if (task >= totalTasks) break;
+    const int b = (int)(task / (unsigned)nF), f = (int)(task - (unsigned)b * (unsigned)nF);
+    const int r0 = 4 * b, nR = min(4, H - r0);
+    const bool hasAbove = b > 0, hasBelow = r0 + nR < H;
+    const int gl = nR - 1;  // the band's last row
+    const int nSteps = W + 2 * (nR - 1);
+    uint8_t* const planeY = A.yuv + (size_t)f * frameBytes;
+    const unsigned mbFrame = (unsigned)f * (unsigned)(W * H);  // (the host API bounds the batch to < 2^31 macroblocks)
+    unsigned* const myProg = A.bandProg + (size_t)f * nBands + b;
+    const unsigned* const upProg = myProg - 1;
+
+    // ---- software pipeline: a step's record is fetched one step ahead (its first word, which decides the
+    // coefficient layout, two steps ahead); its coefficients are fetched right after the previous step's residual
+    // pass, into the registers that pass has just freed. Lane roles are recomputed from an opaque lane id wherever
+    // they are needed: kept live across the step they would cost more registers than the few VALU they take.
+    auto mb_index = [&](int step, int g) -> unsigned {
+      const int x = min(max(step - 2 * g, 0), W - 1);
+      return mbFrame + (unsigned)(min(r0 + g, H - 1) * W + x);
+    };
+    auto load_desc = [&](int step) -> u32x4 {
+      const int l = wv::opaque(lane0);
+      return wv::ld_u128_a2(A.mbs + mb_index(step, l >> 4));
+    };
+    auto load_kind = [&](int step) -> unsigned {
+      const int l = wv::opaque(lane0);
+      return *(const unsigned*)(A.mbs + mb_index(step, l >> 4));
+    };
+    u32x4 cA0, cA1, cB0, cB1;
+    int dcA, dcB;
+    cB0 = cB1 = u32x4{0, 0, 0, 0};
+    dcB = 0;
+    auto load_coefs_luma = [&](int step, unsigned d0) {
+      const int l = wv::opaque(lane0);
+      const int i = l & 15;
+      const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);
+      const int kind = (int)(d0 & 0xffu);
+      const uint8_t* base = (const uint8_t*)A.coeffs + (size_t)mb_index(step, l >> 4) * 768u;
+      // Intra16x16: [DC 16][blk x AC 15]; the lane takes the 16 entries that END with its block's 15 AC, so list
+      // position k (1..15) is AC k-1 (pred16x16.rs:33-46) and entry 0 is replaced by the DC term
+      const int off = kind == 2 ? 30 * (i + 1) : 32 * i;
+      cA0 = wv::ld_u128_a2(base + off);
+      cA1 = wv::ld_u128_a2(base + off + 16);
+      dcA = *(const int16_t*)(base + 2 * ZZ4IDX(zby, zbx));
+    };
+    auto load_coefs_chroma = [&](int step) {
+      const int l = wv::opaque(lane0);
+      if (l < 32) {
+        const int cpl = (l >> 2) & 1, cblk = l & 3;
+        const uint8_t* bc = (const uint8_t*)A.coeffs + (size_t)mb_index(step, (l >> 3) & 3) * 768u;
+        const int offc = 2 * (259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
+        cB0 = wv::ld_u128_a2(bc + offc);
+        cB1 = wv::ld_u128_a2(bc + offc + 16);
+        dcB = *(const int16_t*)(bc + 2 * (256 + 64 * cpl + cblk));
+      }
+    };
+    u32x4 dN1 = load_desc(0);
+    unsigned kN2 = load_kind(1);
+    load_coefs_luma(0, dN1.x);
+    load_coefs_chroma(0);
+
+    int Mprev = 2;           // derived modes of the macroblock to the left on the raster block grid
+    unsigned upKnown = 0;    // what this wave knows of the band above's progress
+    int nStPrev = 0;         // global stores issued in the previous step (wave-uniform)
+    unsigned published = 0;
+
+    for (int s = 0; s < nSteps; s++) {
+      const u32x4 dCur = dN1;
+      const unsigned kN1 = kN2;  // first record word of step s+1
+      // lane roles (see the pipeline comment above)
+      const int lane = wv::opaque(lane0);
+      const int g = lane >> 4, i = lane & 15;
+      const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
+      const int rbx = i & 3, rby = i >> 2;                                              // mode grid: raster
+      const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;           // chroma lane-per-block (lanes 0..31)
+      const int ccx = cblk & 1, ccy = cblk >> 1;
+      const bool chromaLane = lane < 32;
+      const int ch = (i >> 3) & 1, cp = i & 7;                                          // Intra4x4 chain: block half, pixel pair
+      const int tile = ws + S_TILE + TILE_BYTES * g;
+      const int ringMine = ws + S_RING + RING_ROW * g;         // lines of the row above row g
+      const int ringBelow = ws + S_RING + RING_ROW * (g + 1);  // where row g publishes for row g+1 (g < 3)
+      const int r = r0 + g, rC = r0 + gc;
+      const bool rowOk = g < nR, rowOkC = gc < nR;
+      const bool mbB = r > 0, mbBC = rC > 0;
+      const int x = s - 2 * g, xC = s - 2 * gc;
+      const bool valid = rowOk && x >= 0 && x < W, validC = rowOkC && xC >= 0 && xC < W;
+      const int slot = s & 1;  // (x & 1 for every row)
+
+      // ---- publish: everything older than the previous step's stores has completed, in particular the
+      // write-through bottom lines of step s-2 (vmcnt counts loads and stores together, in order)
+      if (hasBelow) {
+        wv::wait_vm(nStPrev);
+        const int done = min(max(s - 2 - 2 * gl + 1, 0), W);
+        if ((unsigned)done > published) {
+          if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
+          published = (unsigned)done;
+        }
+      }
+      // ---- band above: make sure its last row has finished macroblock s+1 (neighbour C of row 0), then fetch
+      // that macroblock's bottom lines into row 0's ring; the progress word for the next step is fetched too
+      unsigned lineV = 0;
+      const bool needUp = hasAbove && s < W;
+      if (needUp) {
+        const unsigned need = (unsigned)min(s + 2, W);
+        while (upKnown < need) {
+          unsigned v = 0;
+          if (lane == 0) v = wv::ld_sc1(upProg);
+          upKnown = (unsigned)wv::rfl((int)v);
+          if (upKnown < need) wv::sleep_long();
+        }
+        wv::compiler_fence();
+        // lanes 0..8: macroblock s+1 (0..3 Y, 4..5 Cb, 6..7 Cr, 8 modes); lanes 16..24: macroblock 0 at step 0
+        const int li = lane & 15;
+        const int mbx = lane < 16 ? s + 1 : 0;
+        const bool act = li < 9 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+        if (act) {
+          const unsigned* src;
+          if (li < 4) src = (const unsigned*)(planeY + (size_t)(16 * r0 - 1) * pitchY + 16 * mbx + 4 * li);
+          else if (li < 8) src = (const unsigned*)(planeY + (li < 6 ? offCb : offCr) + (size_t)(8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
+          else src = A.rowModes + (mbFrame + (unsigned)((r0 - 1) * W + mbx));
+          lineV = wv::ld_sc1(src);
+        }
+      }
+      int nSt = 0;
+
+      // ---- record decode (lane-per-block luma organisation: row g) ------------------------------------------
+      int kind = (int)(dCur.x & 0xffu);
+      const int i16mode = (int)((dCur.x >> 8) & 0xffu), cmodeL = (int)((dCur.x >> 16) & 0xffu);
+      int qp = (int)(dCur.x >> 24);
+      const unsigned prevFlags = dCur.y & 0xffffu;
+      const unsigned long long remBits = ((unsigned long long)(dCur.y >> 16)) | ((unsigned long long)dCur.z << 16) |
+                                         ((unsigned long long)(dCur.w & 0xffffu) << 48);
+      if (kind > 2 || (!HAS_I8 && kind == 1) || qp > 51 || i16mode > 3 || cmodeL > 3) {
+        if (valid && i == 0) wv::atomic_or(A.status, 1u);
+        kind = 3;
+        qp = 0;
+      }
+      const bool mbA = x > 0, mbC = mbB && (x + 1 < W);
+      // the same for the chroma organisation (row gc): record word 0 from lane 16*gc
+      const unsigned dC = (unsigned)wv::bperm((int)((unsigned)kind | (dCur.x & 0x00ffff00u) | ((unsigned)qp << 24)), 16 * gc);
+      const int kindC = (int)(dC & 0xffu), cmode = (int)((dC >> 16) & 0xffu), qpC = (int)(dC >> 24);
+      const bool mbAC = xC > 0;
+
+      // ================= residuals ================================================================================
+      unsigned rA[8];
+      {
+        // Intra16x16 luma DC: 8.5.10 (pred16x16.rs:428-482). Lane (bx,by) holds c[by][bx]; f = A c A = P (H c H) P^T
+        // with H the natural-order Hadamard (butterflies over the lane bits) and A row k = H row s(k), s = [0,2,3,1]
+        long long dcY = 0;
+        if (wv::any(kind == 2)) {
+          int v = dcA;
+          int o = xor1(v);
+          v = (zbx & 1) ? o - v : v + o;
+          o = xor4(v, (i & 4) != 0);
+          v = (zbx & 2) ? o - v : v + o;
+          o = xor2(v);
+          v = (zby & 1) ? o - v : v + o;
+          o = xor8(v);
+          v = (zby & 2) ? o - v : v + o;
+          const int sxx = (0x1320 >> (4 * zbx)) & 3, syy = (0x1320 >> (4 * zby)) & 3;
+          const int fv = wv::bperm(v, (lane & 48) + zidx(sxx, syy));
+          // qp >= 36: (f*LS) << (qp/6-6), else (f*LS + 2^(5-qp/6)) >> (6-qp/6)   (pred16x16.rs:465-479)
+          const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
+          const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
+          const long long prod = (long long)fv * ls00;
+          dcY = qd >= 6 ? prod * (1ll << (qd - 6)) : (prod + (1ll << (5 - qd))) >> (6 - qd);
+        }
+        const int qm = qp - 6 * ((qp * 43) >> 8);
+        residual_pass(cA0, cA1, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp), rA);
+        if (kind == 3) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) rA[k] = 0;
+        }
+      }
+      load_coefs_luma(s + 1, kN1);  // (into the registers the pass above has just freed)
+      // Intra4x4 macroblocks: the chain reads its residuals from LDS, [blkIdx][y][x]
+      if (kind == 0) {
+        wv::lds_st128(ws + S_RES + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
+        wv::lds_st128(ws + S_RES + 512 * g + 32 * i + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
+      }
+
+      // ================= neighbour lines of the row above ========================================================
+      // row 0 of a band below another: this step's fetched macroblock goes into the ring
+      if (needUp) {
+        const int li = lane & 15;
+        const int mbx = lane < 16 ? s + 1 : 0;
+        const bool act = li < 9 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+        if (act) wv::lds_st32(ws + S_RING + RING_ENT * (mbx & 3) + 4 * li, lineV);
+      }
+      wv::wave_sync();
+      // top border of the luma tile: corner dword of x-1, 16 bytes of x, 8 bytes of x+1
+      if (i < 7) {
+        const int e = i == 0 ? x - 1 : (i < 5 ? x : x + 1);
+        const int so = i == 0 ? 12 : (i < 5 ? 4 * (i - 1) : 4 * (i - 5));
+        const unsigned v = wv::lds_u32(ringMine + RING_ENT * (e & 3) + so);
+        wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
+      }
+      wv::wave_sync();
+
+      // ================= Intra4x4 prediction modes (8.3.1.1, pred4x4.rs:363-427) ==================================
+      // mode grid = raster block grid, one DPP row per macroblock. Relaxation: after sweep k every block with
+      // bx + by <= k is final.
+      int Mcur = 2;
+      const bool anyI4 = wv::any(valid && kind == 0);
+      if (anyI4) {
+        const int mzb = zidx(rbx, rby);
+        const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
+        const bool prev = ((prevFlags >> mzb) & 1u) != 0;
+        const unsigned upM = mbB ? wv::lds_u32(ringMine + RING_ENT * (x & 3) + 32) : 0x02020202u;
+        const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
+        const int Lb = wv::dpp<DPP_ROW_SHL(3)>(Mprev, Mprev);
+        const bool unav = (rbx == 0 && !mbA) || (rby == 0 && !mbB);
+        int M = 2;
+#pragma unroll
+        for (int itr = 0; itr < 7; itr++) {
+          int Am = wv::dpp<DPP_QUAD(0, 0, 1, 2)>(M, M);
+          if (rbx == 0) Am = mbA ? Lb : 2;
+          const int Bm = wv::dpp<DPP_ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
+          const int pm = unav ? 2 : min(Am, Bm);
+          M = prev ? pm : (rem < pm ? rem : rem + 1);
+        }
+        int Mp = M;
+        {
+          // quirk Q4: a mode whose reference samples are missing leaves the zero-initialised prediction
+          const bool topAv = rby > 0 || mbB, leftAv = rbx > 0 || mbA;
+          const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
+          const int req = (int)((0x217771021ull >> (4 * M)) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
+          if ((req & ~have) != 0) Mp = 9;
+          // modes 3 and 7 without a top-right block: T4..T7 := T3 (table rows 10 and 11)
+          const unsigned trBlocks = 0x5750u | (mbB ? 0x7u : 0u) | (mbC ? 0x8u : 0u);
+          if (!((trBlocks >> i) & 1u)) Mp = Mp == 3 ? 10 : Mp == 7 ? 11 : Mp;
+        }
+        if (kind == 0) {
+          Mcur = M;
+          const int t = rbx + 2 * rby;
+          const int hh = rby != stepByLo(t) ? 1 : 0;
+          wv::lds_st8(ws + S_MSEQ + 24 * g + 12 * hh + t, (unsigned)Mp);
+        }
+      }
+
+      // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
+      if (wv::any(valid && kind >= 2)) {
+        const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
+        const unsigned lw = wv::lds_u32(ws + S_LEFTY + 16 * g + 4 * zby);
+        unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
+        {
+          // DC: one reduction over the row group of the available sums
+          int sm = ((zby == 0 && mbB) ? (int)wv::sad4(tw) : 0) + ((zbx == 0 && mbA) ? (int)wv::sad4(lw) : 0);
+          sm += xor8(sm);
+          sm += xor4(sm, (i & 4) != 0);
+          sm += xor2(sm);
+          sm += xor1(sm);
+          const int v = (mbA && mbB) ? (sm + 16) >> 5 : (mbA || mbB) ? (sm + 8) >> 4 : 128;
+          if (i16mode == 2) src = (unsigned)v * 0x01010101u;
+        }
+        if (i16mode == 0) {
+          src = mbB ? tw : 0u;
+          selA = 0x0c010c00u;
+          selB = 0x0c030c02u;
+          inc = 0;
+        } else if (i16mode == 1) {
+          if (!mbA) src = 0;
+        } else if (i16mode == 3) {
+          src = 0;
+        }
+        unsigned p01[4], p23[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          p01[k] = wv::perm(src, src, selA + inc * k);
+          p23[k] = wv::perm(src, src, selB + inc * k);
+        }
+        if (wv::any(valid && kind == 2 && i16mode == 3)) {
+          // plane (:366-424): lanes 0..7 of the row group: horizontal terms, 8..15: vertical terms
+          const int k = i & 7;
+          const int tr0 = tile + 8 + 16 * slot, lf = ws + S_LEFTY + 16 * g;
+          const int corner = (int)wv::lds_u8(tr0 - 1);
+          const int ha = (int)wv::lds_u8(tr0 + 8 + k), hb = k == 7 ? corner : (int)wv::lds_u8(tr0 + 6 - k);
+          const int va = (int)wv::lds_u8(lf + 8 + k), vb = k == 7 ? corner : (int)wv::lds_u8(lf + 6 - k);
+          int term = (k + 1) * (i < 8 ? ha - hb : va - vb);
+          term += xor1(term);
+          term += xor2(term);
+          term += xor4(term, (i & 4) != 0);  // lanes 0..7: H, lanes 8..15: V
+          const int hs = wv::bperm(term, lane & 48), vs = wv::bperm(term, (lane & 48) + 8);
+          if (kind == 2 && i16mode == 3 && mbA && mbB) {
+            const int a = 16 * ((int)wv::lds_u8(lf + 15) + (int)wv::lds_u8(tr0 + 15));
+            const int bq = (5 * hs + 32) >> 6, c = (5 * vs + 32) >> 6;
+            const int base = a + bq * (4 * zbx - 7) + c * (4 * zby - 7) + 16;
+            const unsigned b01 = ((unsigned)base & 0xffffu) | ((unsigned)(base + bq) << 16);
+            const unsigned step2 = ((unsigned)(2 * bq) & 0xffffu) | ((unsigned)(2 * bq) << 16);
+            const unsigned cc = ((unsigned)c & 0xffffu) | ((unsigned)c << 16);
+            unsigned q01 = b01, q23 = wv::pk_add(b01, step2);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              const unsigned u01 = wv::sat_pk_u8(wv::pk_ashr5(q01)), u23 = wv::sat_pk_u8(wv::pk_ashr5(q23));
+              p01[kk] = wv::perm(0u, u01, 0x0c010c00u);
+              p23[kk] = wv::perm(0u, u23, 0x0c010c00u);
+              q01 = wv::pk_add(q01, cc);
+              q23 = wv::pk_add(q23, cc);
+            }
+          }
+        }
+        if (kind >= 2) {
+          if (kind == 3) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
+          }
+          const int dst = tile + TILE_STRIDE * (4 * zby + 1) + 8 + 16 * slot + 4 * zbx;
+#pragma unroll
+          for (int k = 0; k < 4; k++) wv::lds_st32(dst + TILE_STRIDE * k, recon_row(p01[k], p23[k], rA[2 * k], rA[2 * k + 1]));
+        }
+      }
+
+      // ================= chroma residuals ==========================================================================
+      unsigned rB[8];
+      {
+        // chroma DC 2x2 (8.5.11, trans_chroma.rs:369-415) over the four block lanes of a plane, then the AC pass.
+        // The LevelScale table is luma's (quirk Q3).
+        const int qc = (int)wv::lds_u8(ldsBase + T_QPC + 52 * cpl + qpC);
+        const int qd = (qc * 43) >> 8, qm = qc - 6 * qd;
+        int v = dcB;
+        int o = xor1(v);
+        v = (cblk & 1) ? o - v : v + o;
+        o = xor2(v);
+        v = (cblk & 2) ? o - v : v + o;
+        const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
+        const long long dcC = (((long long)v * ls00) * (1ll << qd)) >> 5;   // trans_chroma.rs:413
+        residual_pass(cB0, cB1, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), rB);
+        if (kindC == 3) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) rB[k] = 0;
+        }
+      }
+      load_coefs_chroma(s + 1);
+      // ... and the record of step s+1, the first record word of step s+2
+      dN1 = load_desc(s + 1);
+      kN2 = load_kind(s + 2);
+
+      // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (row gc, plane, block) ===================
+      {
+        const int ringC = ws + S_RING + RING_ROW * gc + 16 + 8 * cpl;
+        const int leftC = ws + S_LEFTC + 16 * gc + 8 * cpl;
+        const unsigned tw = wv::lds_u32(ringC + RING_ENT * (xC & 3) + 4 * ccx);
+        const unsigned lw = wv::lds_u32(leftC + 4 * ccy);
+        unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
+        if (cmode == 0) {
+          const int st = (int)wv::sad4(tw), sl = (int)wv::sad4(lw);
+          // trans_chroma.rs:168-286 incl. quirk Q2 (`> 0` where the spec means "available"):
+          //   blocks (0,0),(4,4): both -> 8-sample mean; left only -> left; top only needs every top sample > 0
+          //   block (4,0): top, else left if its 4th sample > 0;  block (0,4): left if its 4th sample > 0, else top if ...
+          const bool nz = (((tw - 0x01010101u) & ~tw) & 0x80808080u) == 0u;
+          const bool tAll = mbBC && nz, t3 = mbBC && (tw >> 24) != 0, l3 = mbAC && (lw >> 24) != 0;
+          const int vT = (st + 2) >> 2, vL = (sl + 2) >> 2, vB = (st + sl + 4) >> 3;
+          const int vDiag = (mbAC && mbBC) ? vB : mbAC ? vL : tAll ? vT : 128;
+          const int vTR = mbBC ? vT : l3 ? vL : 128;
+          const int vBL = l3 ? vL : t3 ? vT : 128;
+          const int v = ccx == ccy ? vDiag : ccx == 1 ? vTR : vBL;
+          src = (unsigned)v * 0x01010101u;
+        } else if (cmode == 1) {  // horizontal (zero without neighbour A: quirk Q4)
+          if (!mbAC) src = 0;
+        } else if (cmode == 2) {  // vertical
+          src = mbBC ? tw : 0u;
+          selA = 0x0c010c00u;
+          selB = 0x0c030c02u;
+          inc = 0;
+        } else {
+          src = 0;  // plane: below
+        }
+        unsigned p01[4], p23[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          p01[k] = wv::perm(src, src, selA + inc * k);
+          p23[k] = wv::perm(src, src, selB + inc * k);
+        }
+        if (wv::any(chromaLane && validC && kindC != 3 && cmode == 3)) {
+          // plane (:319-363): H = sum (k+1)(T[4+k] - T[2-k]), V likewise on the left column; T[-1] = L[-1] = corner
+          const int k = cblk;
+          const int rT = ringC + RING_ENT * (xC & 3);
+          const int corner = (int)wv::lds_u8(ringC + RING_ENT * ((xC - 1) & 3) + 7);
+          const int ha = (int)wv::lds_u8(rT + 4 + k), hb = k == 3 ? corner : (int)wv::lds_u8(rT + 2 - k);
+          const int va = (int)wv::lds_u8(leftC + 4 + k), vb = k == 3 ? corner : (int)wv::lds_u8(leftC + 2 - k);
+          int hs = (k + 1) * (ha - hb), vs = (k + 1) * (va - vb);
+          hs += xor1(hs);
+          hs += xor2(hs);
+          vs += xor1(vs);
+          vs += xor2(vs);
+          if (cmode == 3 && mbAC && mbBC) {
+            const int a = 16 * ((int)wv::lds_u8(leftC + 7) + (int)wv::lds_u8(rT + 7));
+            const int bq = (34 * hs + 32) >> 6, c = (34 * vs + 32) >> 6;
+            // pixel (x, y) of the plane: clip255((a + b (x-3) + c (y-3) + 16) >> 5); all terms fit 16 bits
+            const int base = a + bq * (4 * ccx - 3) + c * (4 * ccy - 3) + 16;
+            const unsigned b01 = ((unsigned)base & 0xffffu) | ((unsigned)(base + bq) << 16);
+            const unsigned step2 = ((unsigned)(2 * bq) & 0xffffu) | ((unsigned)(2 * bq) << 16);
+            const unsigned cc = ((unsigned)c & 0xffffu) | ((unsigned)c << 16);
+            unsigned q01 = b01, q23 = wv::pk_add(b01, step2);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              const unsigned u01 = wv::sat_pk_u8(wv::pk_ashr5(q01)), u23 = wv::sat_pk_u8(wv::pk_ashr5(q23));
+              p01[kk] = wv::perm(0u, u01, 0x0c010c00u);
+              p23[kk] = wv::perm(0u, u23, 0x0c010c00u);
+              q01 = wv::pk_add(q01, cc);
+              q23 = wv::pk_add(q23, cc);
+            }
+          }
+        }
+        if (kindC == 3) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
+        }
+        if (chromaLane) {
+          const int st = ws + S_STC + 256 * gc + 128 * cpl + 16 * (4 * ccy) + 8 * slot + 4 * ccx;
+#pragma unroll
+          for (int k = 0; k < 4; k++) wv::lds_st32(st + 16 * k, recon_row(p01[k], p23[k], rB[2 * k], rB[2 * k + 1]));
+        }
+      }
+
+      wv::wave_sync();
+
+      // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================
+      // lane = (row g, block half ch, pixel pair cp): pixels (2*(cp&1) + {0,1}, cp>>1) of the step's block
+      if (anyI4) {
+        const bool mine = valid && kind == 0;
+        const int px = 2 * (cp & 1), py = cp >> 1;
+        const int seqA = ws + S_MSEQ + 24 * g + 12 * ch;
+        const int tOrg = tile + 8 + 16 * slot;   // row y = -1, x = 0 of the macroblock
+        const int resB = ws + S_RES + 512 * g + 4 * cp;
+        const int entB = ldsBase + T_T4E + 8 * cp;
+#define I4_STEP(T)                                                                                              \
+        {                                                                                                         \
+          constexpr int by0 = stepByLo(T), bx0 = (T) - 2 * by0;                                                   \
+          constexpr bool two = by0 + 1 <= stepByHi(T);                                                            \
+          constexpr int bx1 = two ? bx0 - 2 : bx0, by1 = two ? by0 + 1 : by0;                                     \
+          const bool act = mine && (two || ch == 0);                                                              \
+          const int bx = ch ? bx1 : bx0, by = ch ? by1 : by0;                                                     \
+          const int org = tOrg + TILE_STRIDE * 4 * by + 4 * bx - 1;  /* block origin - one row - one column */    \
+          const unsigned m = wv::lds_u8(seqA + (T));                                                              \
+          const u32x2 en = wv::lds_u64(entB + 64 * (int)min(m, 11u));                                             \
+          const unsigned rr = wv::lds_u32(resB + 32 * (ch ? zidx(bx1, by1) : zidx(bx0, by0)));                    \
+          const int a0 = (int)wv::lds_u8(org + (int)((en.x >> 8) & 0xffu)), a1 = (int)wv::lds_u8(org + (int)((en.x >> 16) & 0xffu)); \
+          const int a2 = (int)wv::lds_u8(org + (int)(en.x >> 24));                                                \
+          const int b0 = (int)wv::lds_u8(org + (int)((en.y >> 8) & 0xffu)), b1 = (int)wv::lds_u8(org + (int)((en.y >> 16) & 0xffu)); \
+          const int b2 = (int)wv::lds_u8(org + (int)(en.y >> 24));                                                \
+          int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                       \
+          int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                       \
+          if (wv::any(act && (en.x & 32u) != 0)) {                                                                \
+            /* DC (pred4x4.rs:116-167) */                                                                         \
+            const unsigned top = wv::lds_u32(org + 1);                                                            \
+            const int l0 = (int)wv::lds_u8(org + TILE_STRIDE), l1 = (int)wv::lds_u8(org + 2 * TILE_STRIDE);       \
+            const int l2 = (int)wv::lds_u8(org + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(org + 4 * TILE_STRIDE);   \
+            const int sumT = (int)wv::sad4(top), sumL = l0 + l1 + l2 + l3;                                        \
+            const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA;                                             \
+            const int dc = (topAv && leftAv) ? (sumT + sumL + 4) >> 3 : leftAv ? (sumL + 2) >> 2 : topAv ? (sumT + 2) >> 2 : 128; \
+            if (en.x & 32u) pa = pb = dc;                                                                         \
+          }                                                                                                       \
+          const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));              \
+          if (act) wv::lds_st16(org + TILE_STRIDE * (py + 1) + 1 + px, o);                                        \
+          wv::wave_sync();                                                                                        \
+        }
+        I4_STEP(0) I4_STEP(1) I4_STEP(2) I4_STEP(3) I4_STEP(4) I4_STEP(5) I4_STEP(6) I4_STEP(7) I4_STEP(8) I4_STEP(9)
+#undef I4_STEP
+      }
+
+      // ================= write-out ================================================================================
+      // bottom lines and modes for the row below (ring) or the band below (write-through)
+      const unsigned m4 = [&]() {
+        unsigned v = (unsigned)Mcur << (8 * (i & 3));
+        v |= (unsigned)xor1((int)v);
+        v |= (unsigned)xor2((int)v);
+        return v;  // lanes 12..15 of the row group: the four bottom-row modes
+      }();
+      {
+        // lanes of row g: 0..3 Y dwords, 4..5 Cb, 6..7 Cr (bottom line), 12: modes
+        const int stc = ws + S_STC + 256 * g;
+        unsigned v = 0;
+        if (i < 4) v = wv::lds_u32(tile + TILE_STRIDE * 16 + 8 + 16 * slot + 4 * i);
+        else if (i < 8) v = wv::lds_u32(stc + 128 * ((i >> 1) & 1) + 16 * 7 + 8 * slot + 4 * (i & 1));
+        else if (i == 12) v = m4;
+        const bool lineLane = i < 8 || i == 12;
+        const int fo = i < 8 ? 4 * i : 32;
+        if (valid && lineLane && g < 3 && g < gl) wv::lds_st32(ringBelow + RING_ENT * (x & 3) + fo, v);
+        const bool toGlobal = hasBelow && g == gl;
+        if (wv::any(valid && toGlobal)) {
+          if (valid && toGlobal && lineLane) {
+            unsigned* dst;
+            if (i < 4) dst = (unsigned*)(planeY + (size_t)(16 * r + 15) * pitchY + 16 * x + 4 * i);
+            else if (i < 8) dst = (unsigned*)(planeY + (i < 6 ? offCb : offCr) + (size_t)(8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
+            else dst = A.rowModes + (mbFrame + (unsigned)(r * W + x));
+            wv::st_sc1(dst, v);
+          }
+          nSt++;
+        }
+      }
+      // left neighbour copies: luma column 15 (also the tile's x = -1 border when the next macroblock is slot 0)
+      {
+        const unsigned v = wv::lds_u8(tile + TILE_STRIDE * (i + 1) + 8 + 16 * slot + 15);
+        wv::lds_st8(ws + S_LEFTY + 16 * g + i, v);
+        if (slot == 1) wv::lds_st8(tile + TILE_STRIDE * (i + 1) + 7, v);
+        const int pl = i >> 3, yy = i & 7;
+        const unsigned c = wv::lds_u8(ws + S_STC + 256 * g + 128 * pl + 16 * yy + 8 * slot + 7);
+        wv::lds_st8(ws + S_LEFTC + 16 * g + 8 * pl + yy, c);
+      }
+      Mprev = valid ? Mcur : 2;
+      wv::wave_sync();
+      // flush the staged rows: every second macroblock, or at the end of a row. 32 (luma) / 16 (chroma) contiguous
+      // bytes per pixel row. The bottom lines of a band that has a band below were already written through.
+      {
+        const bool flushMine = valid && (slot == 1 || x == W - 1);
+        if (wv::any(flushMine)) {
+#pragma unroll
+          for (int it = 0; it < 2; it++) {
+            const int q = lane + 64 * it;
+            const int fg = q >> 5, fy = (q >> 1) & 15, half = q & 1;
+            const int fx = s - 2 * fg, xp = fx & ~1;
+            const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && xp + half <= fx &&
+                            !(hasBelow && fg == gl && fy == 15);
+            const int src = ws + S_TILE + TILE_BYTES * fg + TILE_STRIDE * (fy + 1) + 8 + 16 * half;
+            const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
+            if (ok) wv::st_g128(planeY + (size_t)(16 * (r0 + fg) + fy) * pitchY + 16 * (xp + half), u32x4{lo.x, lo.y, hi.x, hi.y});
+          }
+          {
+            const int fg = lane >> 4, pl = (lane >> 3) & 1, fy = lane & 7;
+            const int fx = s - 2 * fg, xp = fx & ~1;
+            const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && !(hasBelow && fg == gl && fy == 7);
+            const u32x4 v = wv::lds_u128(ws + S_STC + 256 * fg + 128 * pl + 16 * fy);
+            uint8_t* dst = planeY + (pl ? offCr : offCb) + (size_t)(8 * (r0 + fg) + fy) * pitchC + 8 * xp;
+            if (ok) {
+              if (xp + 1 <= fx) wv::st_g128(dst, v);
+              else wv::st_g64(dst, u32x2{v.x, v.y});
+            }
+          }
+          nSt += 4;
+        }
+      }
+      nStPrev = nSt;
+      wv::wave_sync();
+    }
+    // the band is complete once its last stores have been written through
+    if (hasBelow) {
+      wv::wait_vm(0);
+      if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
+    }
+  }
+}
+
+}  // namespace band
+}  // namespace dryv

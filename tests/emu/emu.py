@@ -1,0 +1,42 @@
+"""ctypes loader for the band-kernel CPU emulator (tests/emu/band_emu.cpp). Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libdryv_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+_lib = None
+
+
+def build(force=False):
+    csrc = os.path.join(HERE, "..", "..", "dryv_amd", "csrc")
+    deps = [os.path.join(HERE, "band_emu.cpp")] + [os.path.join(csrc, f) for f in
+                                                    ("band_kernel.h", "wave.h", "kparams.h", "recon_params.h")]
+    if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        r = subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DDRYV_EMU", "-Wall",
+                            "-Wno-unused-function", "-o", SO, deps[0]], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("emulator build failed:\n" + r.stdout)
+    return SO
+
+
+def reconstruct(fp, n_frames, mbs, coeffs):
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.dryv_emu_reconstruct.restype = C.c_int
+        _lib.dryv_emu_reconstruct.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    mbs = np.ascontiguousarray(mbs)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    n_mbs = n_frames * fp.pic_width_in_mbs * fp.pic_height_in_mbs
+    # padded: the kernel's 16-byte coefficient loads may start up to 2 bytes before a block's first AC entry
+    yuv = np.zeros(n_mbs * 384, dtype=np.uint8)
+    status = C.c_uint(0)
+    st = _lib.dryv_emu_reconstruct(C.addressof(fp), n_frames, mbs.ctypes.data, coeffs.ctypes.data, yuv.ctypes.data,
+                                   C.addressof(status))
+    assert st == 0, st
+    return int(status.value), yuv

@@ -1,0 +1,89 @@
+"""The band kernel's source (dryv_amd/csrc/band_kernel.h), compiled for the CPU lane emulator of tests/emu, against
+the oracle. Runs without a GPU: it checks the kernel's index / schedule / arithmetic logic (every lane's program,
+cross-lane operations, LDS layout, band hand-off order); the GPU parity tests (`-m gpu`) remain the proof for the
+machine code. Bit-exact bar. Reference parity itself stays unpinned (see oracle/dryv_oracle.c header)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from dryv_amd import abi, synth
+from util import first_mismatch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+import emu  # noqa: E402
+
+
+def check(fp, frames, mbs, co, expect_status=0):
+    st, want = oracle.reconstruct(fp, frames, mbs, co)
+    st2, got = emu.reconstruct(fp, frames, mbs, co)
+    assert (st != 0) == (expect_status != 0)
+    assert (st2 != 0) == (expect_status != 0)
+    W, H = fp.pic_width_in_mbs, fp.pic_height_in_mbs
+    assert np.array_equal(got, want), first_mismatch(got, want, W, H)
+
+
+CASES = [
+    ("i16_only", 7, 5, 2, dict(i4x4=0.0, i8x8=0.0), {}),
+    ("i4x4_only", 7, 5, 2, dict(i4x4=1.0, i8x8=0.0), {}),
+    ("i8x8_only", 7, 5, 2, dict(i4x4=0.0, i8x8=1.0), dict(transform_8x8=True)),
+    ("c2_mix_small", 12, 9, 2, dict(i4x4=0.7, i8x8=0.0), {}),
+    ("c3_mix_small", 12, 9, 2, dict(i4x4=0.35, i8x8=0.40), dict(transform_8x8=True)),
+    ("single_mb", 1, 1, 3, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
+    ("single_row", 9, 1, 2, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
+    ("single_col", 1, 9, 2, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
+    ("two_cols", 2, 17, 1, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
+    ("all_qp", 10, 8, 2, dict(i4x4=0.5, i8x8=0.3, qp=(0, 51)), dict(transform_8x8=True)),
+    ("dense_big_levels", 8, 6, 2, dict(i4x4=0.5, i8x8=0.3, coded=1.0, p0=0.9, decay4=0.97, decay8=0.99, max_level=2047,
+                                       qp=(0, 51)), dict(transform_8x8=True)),
+    ("illegal_modes_q4", 9, 7, 2, dict(i4x4=0.5, i8x8=0.3, legal_modes_only=False), dict(transform_8x8=True)),
+    ("chroma_qp_offsets", 9, 7, 2, dict(i4x4=0.5, i8x8=0.3, qp=(0, 51)), dict(transform_8x8=True, cqo_cb=-7, cqo_cr=11)),
+    ("zero_residual", 9, 7, 1, dict(i4x4=0.5, i8x8=0.3, coded=0.0), dict(transform_8x8=True)),
+    ("dark_q2_zeros", 9, 7, 2, dict(i4x4=0.4, i8x8=0.2, coded=1.0, p0=0.6, max_level=300, qp=(30, 51)),
+     dict(transform_8x8=True)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_emulated_band_kernel_matches_oracle(case):
+    name, W, H, frames, skw, fkw = case
+    fp = abi.make_frame_params(W, H, **fkw)
+    mbs, co = synth.generate(fp, synth.config(**skw), 100 + CASES.index(case), 0, frames)
+    check(fp, frames, mbs, co)
+
+
+def test_emulated_fuzz():
+    rng = np.random.default_rng(77)
+    for k in range(16):
+        W, H, frames = int(rng.integers(1, 14)), int(rng.integers(1, 11)), int(rng.integers(1, 3))
+        i4 = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+        i8 = min(float(rng.choice([0.0, 0.3])), 1.0 - i4)
+        lo = int(rng.integers(0, 40))
+        flat = rng.random() < 0.5
+        fkw = dict(transform_8x8=i8 > 0, cqo_cb=int(rng.integers(-12, 13)), cqo_cr=int(rng.integers(-12, 13)))
+        if not flat:
+            fkw.update(scaling4x4=rng.integers(4, 48, size=(6, 16)), scaling8x8=rng.integers(4, 48, size=(6, 64)))
+        skw = dict(i4x4=i4, i8x8=i8, qp=(lo, int(rng.integers(lo, 52))), coded=float(rng.choice([0.2, 0.6, 1.0])),
+                   max_level=int(rng.choice([15, 300, 2047])) if flat else 200,
+                   legal_modes_only=bool(rng.random() < 0.7), prev_flag=float(rng.choice([0.1, 0.5, 0.9])))
+        fp = abi.make_frame_params(W, H, **fkw)
+        mbs, co = synth.generate(fp, synth.config(**skw), 2000 + k, k, frames)
+        check(fp, frames, mbs, co)
+
+
+@pytest.mark.parametrize("qp_range", [(0, 24), (25, 40), (41, 51)])
+def test_emulated_full_int16_range_every_qp(qp_range):
+    """The FFI carries int16 coefficients and scaling weights up to 255; the reference computes in 64-bit isize.
+    Blocks whose coefficients exceed the per-qp int32-exactness bound take the kernel's 64-bit pass."""
+    rng = np.random.default_rng(9 + qp_range[0])
+    s4 = rng.integers(1, 256, size=(6, 16))
+    s8 = rng.integers(1, 256, size=(6, 64))
+    for lists in (dict(), dict(scaling4x4=s4, scaling8x8=s8)):
+        fp = abi.make_frame_params(6, 5, transform_8x8=True, **lists)
+        mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3, coded=1.0, p0=0.9, decay4=0.97, decay8=0.99,
+                                                  qp=qp_range), 61, 0, 2)
+        scale = rng.choice([1, 40, 700, 6000], size=(co.shape[0], 1))
+        co = np.clip(co.astype(np.int64) * scale, -32768, 32767).astype(np.int16)
+        check(fp, 2, mbs, co)
