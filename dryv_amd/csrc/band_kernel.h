@@ -9,17 +9,18 @@
 //     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running or done, so
 //     there is no deadlock at any residency. 300 frames x 17 bands = 5100 waves fit the chip at once (5 per SIMD).
 //   * Between bands the hand-off goes through L2 (MI355X_MICROARCH.md "valid forms", sc1 stores + drained flag,
-//     sc1 loads): the band's last row stores its bottom pixel lines and bottom-row modes write-through, and two
-//     steps later -- when a counted s_waitcnt has shown those stores complete -- publishes its progress word. The
-//     band below polls that word one step ahead and fetches one macroblock's lines per step into its ring.
+//     sc1 loads): the band's last row stores its bottom pixel lines and bottom-row modes write-through and, after
+//     the next step's luma residuals -- when s_waitcnt vmcnt(0) has shown those stores complete -- publishes its
+//     progress word. The band below reads that word one step ahead and fetches one macroblock's lines per step.
 //
 // Inside a step (4 macroblocks)
 //   * residual: ONE LANE PER 4x4 BLOCK. The lane loads its block's 16 coefficients (32 contiguous bytes of the
 //     reference's list order) straight into registers, so the inverse zig-zag is register renaming, both butterfly
 //     passes are in-lane, and no transpose or LDS traffic exists. Luma: 64 lanes = 4 MB x 16 blocks; chroma: 32
 //     lanes = 4 MB x 2 planes x 4 blocks. Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP.
-//     int32 arithmetic with a per-qp coefficient bound (KParams::thr4); a wave whose pass exceeds it re-runs the
-//     pass in int64 (reference: isize), so the result is the reference's for every int16 input.
+//     int32 arithmetic with a per-qp coefficient bound (KParams::thr4). A block beyond it flags the batch, and the
+//     host re-runs the batch with the WIDE build of this kernel, whose passes switch to int64 (reference: isize)
+//     for such waves: the result is the reference's for every int16 input.
 //   * Intra16x16 and chroma prediction stay in the lane-per-block layout (residuals never leave registers): V, H
 //     and DC are one v_perm_b32 byte-select per pixel pair, plane is packed 16-bit arithmetic.
 //   * Intra4x4: prediction modes by the 7-sweep DPP relaxation over the block grid (one DPP row per macroblock),
@@ -61,6 +62,38 @@ constexpr int S_BYTES = 6784;                   // (64-byte multiple)
 static_assert(S_MSEQ + 96 <= S_BYTES, "scratch layout");
 
 constexpr int WAVES_PER_WG = 5;
+constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a progress word (about a second) before a band gives up
+
+// Diagnostic builds only. -DDRYV_BAND_PROFILE (tools/band_phases.py): per-wave cycle sums per phase of the step.
+// -DDRYV_BAND_TRACE (tools/band_trace.py): breadcrumbs only. Both write to a buffer of their own; the shipped library
+// contains none of this.
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_BAND_TRACE)
+#define DRYV_BAND_TRACE
+#endif
+#define BAND_NPH 16
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+#define PH(k)                                                     \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                           \
+    phAcc[k] += now_ - phT;                                       \
+    phT = now_;                                                   \
+  } while (0)
+#else
+#define PH(k) do { } while (0)
+#endif
+// breadcrumbs: word k of this wave's 8-word trace record (behind the phase sums), written through so that a host
+// thread can read them while the kernel is still running
+#if defined(DRYV_BAND_TRACE) && !defined(DRYV_EMU)
+#define TRACE(k, val)                                                                                                 \
+  do {                                                                                                                \
+    if (lane0 == 0 && A.profile)                                                                                      \
+      wv::st_sc1((unsigned*)(A.profile + (size_t)65536 * BAND_NPH) + (size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * 8 + (k), \
+                 (unsigned)(val));                                                                                    \
+  } while (0)
+#else
+#define TRACE(k, val) do { } while (0)
+#endif
 
 struct Args {
   const dryv_mb_desc* mbs;
@@ -70,6 +103,8 @@ struct Args {
   unsigned* bandProg;   // [frame][band]: macroblocks of the band's last row whose bottom lines are visible
   unsigned* rowModes;   // [mb]: bottom-row Intra4x4/8x8 modes (only rows that end a band are written)
   unsigned* taskCounter;
+  unsigned long long* profile;  // DRYV_BAND_PROFILE builds only
+  int waveBase;                 // (global index of the workgroup's first wave, for the same)
 };
 
 // zig-zag (frame/mod.rs:185-209): list index of matrix element (row, col)
@@ -225,20 +260,28 @@ WV int max_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
   return m;
 }
 
-// One pass of lane-per-block residuals. big = this lane's block may overflow int32 -> the whole wave takes the
-// 64-bit instantiation (wave-uniform branch; never taken for conformant streams).
+// One pass of lane-per-block residuals. big = this lane's block may overflow int32. WIDE build: the whole wave then
+// takes the 64-bit path (wave-uniform branch). Fast build: the batch is flagged (status bit 1) and the host re-runs it
+// with the WIDE build before anything is reported -- the fast kernel carries no 64-bit code, which would cost it its
+// register budget; no conformant stream ever takes this route.
+template <bool WIDE>
 WV void residual_pass(const u32x4 c0, const u32x4 c1, int lsAddr, int qp, bool useDc, long long dcVal, int thr,
-                      unsigned out[8]) {
+                      unsigned* status, unsigned out[8]) {
   const int qd = (qp * 43) >> 8;
   const int shl = max(qd - 4, 0), shr = max(4 - qd, 0), rnd = qd < 4 ? (1 << (3 - qd)) : 0;
   bool big = false;
   if (wv::any(thr != 0xFFFF)) big = thr != 0xFFFF && max_abs16(c0, c1, useDc) > thr;
   if (useDc && (dcVal > (1ll << 26) || dcVal < -(1ll << 26))) big = true;
-  if (wv::any(big)) idct4x4_wide(c0, c1, lsAddr, shl, rnd, shr, useDc, dcVal, out);
-  else {
-    const u32x4 l0 = wv::lds_u128(lsAddr), l1 = wv::lds_u128(lsAddr + 16);
-    idct4x4<int>(c0, c1, l0, l1, shl, rnd, shr, useDc, (int)dcVal, out);
+  if (WIDE) {
+    if (wv::any(big)) {
+      idct4x4_wide(c0, c1, lsAddr, shl, rnd, shr, useDc, dcVal, out);
+      return;
+    }
+  } else if (big) {
+    wv::atomic_or(status, 2u);
   }
+  const u32x4 l0 = wv::lds_u128(lsAddr), l1 = wv::lds_u128(lsAddr + 16);
+  idct4x4<int>(c0, c1, l0, l1, shl, rnd, shr, useDc, (int)dcVal, out);
 }
 
 // lane i ^ 4 and i ^ 8 inside a 16-lane DPP row
@@ -257,9 +300,15 @@ WV unsigned recon_row(unsigned p01, unsigned p23, unsigned r01, unsigned r23) {
 }
 
 // ---- the kernel body: one wave, any number of band tasks -----------------------------------------------------
-template <bool HAS_I8>
+template <bool HAS_I8, bool WIDE>
 WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int ws) {
   const int lane0 = wv::lane_id();
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  unsigned long long phAcc[BAND_NPH];
+  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
+  unsigned long long phT = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   const int W = P.W, H = P.H, nF = P.n_frames;
   const int nBands = (H + 3) >> 2;
   const unsigned totalTasks = (unsigned)nF * (unsigned)nBands;
@@ -268,17 +317,25 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
   const unsigned offCb = (unsigned)W * H * 256u, offCr = offCb + (unsigned)W * H * 64u;
 
   for (;;) {
-    unsigned tsk = 0;
-    if (lane0 == 0) tsk = wv::atomic_inc_task(A.taskCounter);
+    // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
+    // a single-lane conditional in front of a readfirstlane invites the compiler to thread that condition through the
+    // loop, after which the readfirstlane executes under a partial exec mask and returns another lane's value.
+    const unsigned tsk = wv::atomic_add_task(A.taskCounter, lane0 == 0 ? 1u : 0u);
     const unsigned task = (unsigned)wv::rfl((int)tsk);
     if (task >= totalTasks) break;
+    TRACE(0, task + 1u);
     const int b = (int)(task / (unsigned)nF), f = (int)(task - (unsigned)b * (unsigned)nF);
     const int r0 = 4 * b, nR = min(4, H - r0);
     const bool hasAbove = b > 0, hasBelow = r0 + nR < H;
     const int gl = nR - 1;  // the band's last row
     const int nSteps = W + 2 * (nR - 1);
+    // per-frame bases (wave-uniform); everything below addresses them with 32-bit offsets: a frame's planes, records
+    // and coefficients are each < 4 GB (the host API checks)
     uint8_t* const planeY = A.yuv + (size_t)f * frameBytes;
-    const unsigned mbFrame = (unsigned)f * (unsigned)(W * H);  // (the host API bounds the batch to < 2^31 macroblocks)
+    const size_t mbFrame = (size_t)f * (size_t)(W * H);
+    const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
+    const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
+    uint8_t* const modesF = (uint8_t*)(A.rowModes + mbFrame);
     unsigned* const myProg = A.bandProg + (size_t)f * nBands + b;
     const unsigned* const upProg = myProg - 1;
 
@@ -286,17 +343,17 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
     // coefficient layout, two steps ahead); its coefficients are fetched right after the previous step's residual
     // pass, into the registers that pass has just freed. Lane roles are recomputed from an opaque lane id wherever
     // they are needed: kept live across the step they would cost more registers than the few VALU they take.
-    auto mb_index = [&](int step, int g) -> unsigned {
+    auto mb_index = [&](int step, int g) -> unsigned {  // within the frame
       const int x = min(max(step - 2 * g, 0), W - 1);
-      return mbFrame + (unsigned)(min(r0 + g, H - 1) * W + x);
+      return (unsigned)(min(r0 + g, H - 1) * W + x);
     };
     auto load_desc = [&](int step) -> u32x4 {
       const int l = wv::opaque(lane0);
-      return wv::ld_u128_a2(A.mbs + mb_index(step, l >> 4));
+      return wv::ld_u128_a2(mbsF + 16u * mb_index(step, l >> 4));
     };
     auto load_kind = [&](int step) -> unsigned {
       const int l = wv::opaque(lane0);
-      return *(const unsigned*)(A.mbs + mb_index(step, l >> 4));
+      return *(const unsigned*)(mbsF + 16u * mb_index(step, l >> 4));
     };
     u32x4 cA0, cA1, cB0, cB1;
     int dcA, dcB;
@@ -307,23 +364,23 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       const int i = l & 15;
       const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);
       const int kind = (int)(d0 & 0xffu);
-      const uint8_t* base = (const uint8_t*)A.coeffs + (size_t)mb_index(step, l >> 4) * 768u;
+      const unsigned mo = mb_index(step, l >> 4) * 768u;
       // Intra16x16: [DC 16][blk x AC 15]; the lane takes the 16 entries that END with its block's 15 AC, so list
       // position k (1..15) is AC k-1 (pred16x16.rs:33-46) and entry 0 is replaced by the DC term
       const int off = kind == 2 ? 30 * (i + 1) : 32 * i;
-      cA0 = wv::ld_u128_a2(base + off);
-      cA1 = wv::ld_u128_a2(base + off + 16);
-      dcA = *(const int16_t*)(base + 2 * ZZ4IDX(zby, zbx));
+      cA0 = wv::ld_u128_a2(coefF + (mo + (unsigned)off));
+      cA1 = wv::ld_u128_a2(coefF + (mo + (unsigned)off + 16u));
+      dcA = *(const int16_t*)(coefF + (mo + 2u * (unsigned)ZZ4IDX(zby, zbx)));
     };
     auto load_coefs_chroma = [&](int step) {
       const int l = wv::opaque(lane0);
       if (l < 32) {
         const int cpl = (l >> 2) & 1, cblk = l & 3;
-        const uint8_t* bc = (const uint8_t*)A.coeffs + (size_t)mb_index(step, (l >> 3) & 3) * 768u;
-        const int offc = 2 * (259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
-        cB0 = wv::ld_u128_a2(bc + offc);
-        cB1 = wv::ld_u128_a2(bc + offc + 16);
-        dcB = *(const int16_t*)(bc + 2 * (256 + 64 * cpl + cblk));
+        const unsigned mo = mb_index(step, (l >> 3) & 3) * 768u;
+        const unsigned offc = 2u * (unsigned)(259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
+        cB0 = wv::ld_u128_a2(coefF + (mo + offc));
+        cB1 = wv::ld_u128_a2(coefF + (mo + offc + 16u));
+        dcB = *(const int16_t*)(coefF + (mo + 2u * (unsigned)(256 + 64 * cpl + cblk)));
       }
     };
     u32x4 dN1 = load_desc(0);
@@ -331,12 +388,15 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
     load_coefs_luma(0, dN1.x);
     load_coefs_chroma(0);
 
+    PH(0);  // claim, prologue loads
     int Mprev = 2;           // derived modes of the macroblock to the left on the raster block grid
     unsigned upKnown = 0;    // what this wave knows of the band above's progress
-    int nStPrev = 0;         // global stores issued in the previous step (wave-uniform)
-    unsigned published = 0;
+    unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
+    bool flagPend = false;
+    bool linePend = false;   // bottom lines of the band's last row were stored in the previous step, not yet published
 
     for (int s = 0; s < nSteps; s++) {
+      TRACE(1, s + 1);
       const u32x4 dCur = dN1;
       const unsigned kN1 = kN2;  // first record word of step s+1
       // lane roles (see the pipeline comment above)
@@ -358,42 +418,8 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       const bool valid = rowOk && x >= 0 && x < W, validC = rowOkC && xC >= 0 && xC < W;
       const int slot = s & 1;  // (x & 1 for every row)
 
-      // ---- publish: everything older than the previous step's stores has completed, in particular the
-      // write-through bottom lines of step s-2 (vmcnt counts loads and stores together, in order)
-      if (hasBelow) {
-        wv::wait_vm(nStPrev);
-        const int done = min(max(s - 2 - 2 * gl + 1, 0), W);
-        if ((unsigned)done > published) {
-          if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
-          published = (unsigned)done;
-        }
-      }
-      // ---- band above: make sure its last row has finished macroblock s+1 (neighbour C of row 0), then fetch
-      // that macroblock's bottom lines into row 0's ring; the progress word for the next step is fetched too
-      unsigned lineV = 0;
       const bool needUp = hasAbove && s < W;
-      if (needUp) {
-        const unsigned need = (unsigned)min(s + 2, W);
-        while (upKnown < need) {
-          unsigned v = 0;
-          if (lane == 0) v = wv::ld_sc1(upProg);
-          upKnown = (unsigned)wv::rfl((int)v);
-          if (upKnown < need) wv::sleep_long();
-        }
-        wv::compiler_fence();
-        // lanes 0..8: macroblock s+1 (0..3 Y, 4..5 Cb, 6..7 Cr, 8 modes); lanes 16..24: macroblock 0 at step 0
-        const int li = lane & 15;
-        const int mbx = lane < 16 ? s + 1 : 0;
-        const bool act = li < 9 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-        if (act) {
-          const unsigned* src;
-          if (li < 4) src = (const unsigned*)(planeY + (size_t)(16 * r0 - 1) * pitchY + 16 * mbx + 4 * li);
-          else if (li < 8) src = (const unsigned*)(planeY + (li < 6 ? offCb : offCr) + (size_t)(8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
-          else src = A.rowModes + (mbFrame + (unsigned)((r0 - 1) * W + mbx));
-          lineV = wv::ld_sc1(src);
-        }
-      }
-      int nSt = 0;
+      unsigned lineV = 0;
 
       // ---- record decode (lane-per-block luma organisation: row g) ------------------------------------------
       int kind = (int)(dCur.x & 0xffu);
@@ -413,6 +439,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       const int kindC = (int)(dC & 0xffu), cmode = (int)((dC >> 16) & 0xffu), qpC = (int)(dC >> 24);
       const bool mbAC = xC > 0;
 
+      PH(2);  // record decode
       // ================= residuals ================================================================================
       unsigned rA[8];
       {
@@ -438,13 +465,70 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
           dcY = qd >= 6 ? prod * (1ll << (qd - 6)) : (prod + (1ll << (5 - qd))) >> (6 - qd);
         }
         const int qm = qp - 6 * ((qp * 43) >> 8);
-        residual_pass(cA0, cA1, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp), rA);
+        residual_pass<WIDE>(cA0, cA1, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp), A.status, rA);
         if (kind == 3) {
 #pragma unroll
           for (int k = 0; k < 8; k++) rA[k] = 0;
         }
       }
-      load_coefs_luma(s + 1, kN1);  // (into the registers the pass above has just freed)
+      PH(3);  // luma residuals
+      // ---- hand-off traffic, placed here so that nothing in front of the residuals waits for it.
+      // Publish: the previous step ended with the write-through stores of its last-row macroblock's bottom lines (and
+      // the staged row segments). By now they have had a residual pass to drain; once vmcnt says so (everything this
+      // wave has issued is done: loads and stores count together, in order) the macroblock is published.
+      if (linePend) {
+        wv::wait_vm(0);
+        const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
+        if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
+        linePend = false;
+      }
+      if (needUp) {
+        // the band above must have finished macroblock s+1 (neighbour C of row 0) before its lines are fetched. Its
+        // progress word is read one step ahead (flagV), so this normally costs nothing; otherwise poll.
+        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
+        flagPend = false;
+        const unsigned need = (unsigned)min(s + 2, W);
+        unsigned spins = 0;
+        TRACE(2, (s << 16) | need);
+        while (upKnown < need) {
+          const unsigned v = wv::ld_sc1(upProg);  // (all lanes, one address: one request)
+          upKnown = (unsigned)wv::rfl((int)v);
+          if (upKnown < need) {
+            wv::sleep_short();
+            if (++spins > SPIN_LIMIT) {
+              // every spin is bounded: a band above that never gets there is reported (status bit 2 + where), not waited for
+              if (lane == 0) {
+                wv::atomic_or(A.status, 4u);
+                A.status[1] = task;
+                A.status[2] = ((unsigned)s << 16) | need;
+                A.status[3] = upKnown;
+              }
+              upKnown = (unsigned)W;
+            }
+          }
+        }
+        TRACE(3, (s << 16) | upKnown);
+        wv::compiler_fence();
+        // lanes 0..8: macroblock s+1 (0..3 Y, 4..5 Cb, 6..7 Cr, 8 modes); lanes 16..24: macroblock 0 at step 0
+        const int li = lane & 15;
+        const int mbx = lane < 16 ? s + 1 : 0;
+        const bool act = li < 9 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+        if (act) {
+          if (li < 8) {
+            const unsigned off = li < 4 ? (unsigned)((16 * r0 - 1) * pitchY + 16 * mbx + 4 * li)
+                                        : (li < 6 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
+            lineV = wv::ld_sc1((const unsigned*)(planeY + off));
+          } else {
+            lineV = wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mbx)));
+          }
+        }
+        if (upKnown < (unsigned)W) {
+          flagV = wv::ld_sc1(upProg);
+          flagPend = true;
+        }
+      }
+      load_coefs_luma(s + 1, kN1);  // (into the registers the residual pass has just freed)
+      PH(4);  // hand-off traffic, coefficient prefetch
       // Intra4x4 macroblocks: the chain reads its residuals from LDS, [blkIdx][y][x]
       if (kind == 0) {
         wv::lds_st128(ws + S_RES + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
@@ -452,23 +536,22 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       }
 
       // ================= neighbour lines of the row above ========================================================
-      // row 0 of a band below another: this step's fetched macroblock goes into the ring
-      if (needUp) {
+      // (step 0 of a band below another: macroblock 0's lines have only just been requested)
+      if (needUp && s == 0) {
         const int li = lane & 15;
-        const int mbx = lane < 16 ? s + 1 : 0;
-        const bool act = li < 9 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-        if (act) wv::lds_st32(ws + S_RING + RING_ENT * (mbx & 3) + 4 * li, lineV);
+        if (li < 9 && lane >= 16 && lane < 32) wv::lds_st32(ws + S_RING + 4 * li, lineV);
       }
       wv::wave_sync();
-      // top border of the luma tile: corner dword of x-1, 16 bytes of x, 8 bytes of x+1
-      if (i < 7) {
-        const int e = i == 0 ? x - 1 : (i < 5 ? x : x + 1);
-        const int so = i == 0 ? 12 : (i < 5 ? 4 * (i - 1) : 4 * (i - 5));
+      // top border of the luma tile, first part: corner dword of x-1, 16 bytes of x
+      if (i < 5) {
+        const int e = i == 0 ? x - 1 : x;
+        const int so = i == 0 ? 12 : 4 * (i - 1);
         const unsigned v = wv::lds_u32(ringMine + RING_ENT * (e & 3) + so);
         wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
       }
       wv::wave_sync();
 
+      PH(5);  // residual store, top border
       // ================= Intra4x4 prediction modes (8.3.1.1, pred4x4.rs:363-427) ==================================
       // mode grid = raster block grid, one DPP row per macroblock. Relaxation: after sweep k every block with
       // bx + by <= k is final.
@@ -510,6 +593,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         }
       }
 
+      PH(6);  // modes
       // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
       if (wv::any(valid && kind >= 2)) {
         const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
@@ -582,6 +666,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         }
       }
 
+      PH(7);  // Intra16x16
       // ================= chroma residuals ==========================================================================
       unsigned rB[8];
       {
@@ -596,7 +681,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         v = (cblk & 2) ? o - v : v + o;
         const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
         const long long dcC = (((long long)v * ls00) * (1ll << qd)) >> 5;   // trans_chroma.rs:413
-        residual_pass(cB0, cB1, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), rB);
+        residual_pass<WIDE>(cB0, cB1, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), A.status, rB);
         if (kindC == 3) {
 #pragma unroll
           for (int k = 0; k < 8; k++) rB[k] = 0;
@@ -607,6 +692,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       dN1 = load_desc(s + 1);
       kN2 = load_kind(s + 2);
 
+      PH(8);  // chroma residuals, prefetch
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (row gc, plane, block) ===================
       {
         const int ringC = ws + S_RING + RING_ROW * gc + 16 + 8 * cpl;
@@ -687,6 +773,20 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
 
       wv::wave_sync();
 
+      PH(9);  // chroma prediction
+      // ================= top-right neighbour: the fetched macroblock s+1 goes into row 0's ring, then 8 bytes of x+1
+      if (needUp) {
+        const int li = lane & 15;
+        if (li < 9 && lane < 16 && s + 1 < W) wv::lds_st32(ws + S_RING + RING_ENT * ((s + 1) & 3) + 4 * li, lineV);
+        wv::wave_sync();
+      }
+      if (i == 5 || i == 6) {
+        const unsigned v = wv::lds_u32(ringMine + RING_ENT * ((x + 1) & 3) + 4 * (i - 5));
+        wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
+      }
+      wv::wave_sync();
+
+      PH(10);  // top-right copy
       // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================
       // lane = (row g, block half ch, pixel pair cp): pixels (2*(cp&1) + {0,1}, cp>>1) of the step's block
       if (anyI4) {
@@ -696,28 +796,34 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         const int tOrg = tile + 8 + 16 * slot;   // row y = -1, x = 0 of the macroblock
         const int resB = ws + S_RES + 512 * g + 4 * cp;
         const int entB = ldsBase + T_T4E + 8 * cp;
+        // the table rows of all ten steps (they do not depend on pixels), then entry and residual one step ahead
+        const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
+        u32x2 en = wv::lds_u64(entB + 64 * (int)min(sq0 & 0xffu, 11u));
+        unsigned rr = wv::lds_u32(resB);
+#define I4_BLK(T, h) ((h) && (stepByLo(T) + 1 <= stepByHi(T)) ? zidx((T) - 2 * stepByLo(T) - 2, stepByLo(T) + 1) : zidx((T) - 2 * stepByLo(T), stepByLo(T)))
 #define I4_STEP(T)                                                                                              \
         {                                                                                                         \
           constexpr int by0 = stepByLo(T), bx0 = (T) - 2 * by0;                                                   \
           constexpr bool two = by0 + 1 <= stepByHi(T);                                                            \
           constexpr int bx1 = two ? bx0 - 2 : bx0, by1 = two ? by0 + 1 : by0;                                     \
+          constexpr int TN = (T) < 9 ? (T) + 1 : 9;                                                               \
           const bool act = mine && (two || ch == 0);                                                              \
           const int bx = ch ? bx1 : bx0, by = ch ? by1 : by0;                                                     \
           const int org = tOrg + TILE_STRIDE * 4 * by + 4 * bx - 1;  /* block origin - one row - one column */    \
-          const unsigned m = wv::lds_u8(seqA + (T));                                                              \
-          const u32x2 en = wv::lds_u64(entB + 64 * (int)min(m, 11u));                                             \
-          const unsigned rr = wv::lds_u32(resB + 32 * (ch ? zidx(bx1, by1) : zidx(bx0, by0)));                    \
+          const unsigned mN = min(((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu, 11u);          \
+          const u32x2 enN = wv::lds_u64(entB + 64 * (int)mN);                                                     \
+          const unsigned rrN = wv::lds_u32(resB + 32 * (ch ? I4_BLK(TN, 1) : I4_BLK(TN, 0)));                     \
           const int a0 = (int)wv::lds_u8(org + (int)((en.x >> 8) & 0xffu)), a1 = (int)wv::lds_u8(org + (int)((en.x >> 16) & 0xffu)); \
           const int a2 = (int)wv::lds_u8(org + (int)(en.x >> 24));                                                \
           const int b0 = (int)wv::lds_u8(org + (int)((en.y >> 8) & 0xffu)), b1 = (int)wv::lds_u8(org + (int)((en.y >> 16) & 0xffu)); \
           const int b2 = (int)wv::lds_u8(org + (int)(en.y >> 24));                                                \
+          const unsigned top = wv::lds_u32(org + 1);                                                              \
+          const int l0 = (int)wv::lds_u8(org + TILE_STRIDE), l1 = (int)wv::lds_u8(org + 2 * TILE_STRIDE);         \
+          const int l2 = (int)wv::lds_u8(org + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(org + 4 * TILE_STRIDE);     \
           int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                       \
           int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                       \
-          if (wv::any(act && (en.x & 32u) != 0)) {                                                                \
-            /* DC (pred4x4.rs:116-167) */                                                                         \
-            const unsigned top = wv::lds_u32(org + 1);                                                            \
-            const int l0 = (int)wv::lds_u8(org + TILE_STRIDE), l1 = (int)wv::lds_u8(org + 2 * TILE_STRIDE);       \
-            const int l2 = (int)wv::lds_u8(org + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(org + 4 * TILE_STRIDE);   \
+          {                                                                                                       \
+            /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch) */ \
             const int sumT = (int)wv::sad4(top), sumL = l0 + l1 + l2 + l3;                                        \
             const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA;                                             \
             const int dc = (topAv && leftAv) ? (sumT + sumL + 4) >> 3 : leftAv ? (sumL + 2) >> 2 : topAv ? (sumT + 2) >> 2 : 128; \
@@ -725,13 +831,27 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
           }                                                                                                       \
           const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));              \
           if (act) wv::lds_st16(org + TILE_STRIDE * (py + 1) + 1 + px, o);                                        \
+          en = enN;                                                                                               \
+          rr = rrN;                                                                                               \
           wv::wave_sync();                                                                                        \
         }
         I4_STEP(0) I4_STEP(1) I4_STEP(2) I4_STEP(3) I4_STEP(4) I4_STEP(5) I4_STEP(6) I4_STEP(7) I4_STEP(8) I4_STEP(9)
+#undef I4_BLK
 #undef I4_STEP
       }
 
+      TRACE(4, s + 1);
+      PH(11);  // Intra4x4 chain
       // ================= write-out ================================================================================
+      // The prefetched record and coefficients are "used" here, in front of this step's stores: the compiler then
+      // waits for those loads now (they were issued thousands of cycles ago) instead of at the top of the next step,
+      // where its vmcnt(0) would also wait for the stores below.
+      dN1.x = (unsigned)wv::opaque((int)dN1.x); dN1.y = (unsigned)wv::opaque((int)dN1.y);
+      dN1.z = (unsigned)wv::opaque((int)dN1.z); dN1.w = (unsigned)wv::opaque((int)dN1.w);
+      kN2 = (unsigned)wv::opaque((int)kN2);
+      cA0.x = (unsigned)wv::opaque((int)cA0.x); cA1.x = (unsigned)wv::opaque((int)cA1.x); dcA = wv::opaque(dcA);
+      cB0.x = (unsigned)wv::opaque((int)cB0.x); cB1.x = (unsigned)wv::opaque((int)cB1.x); dcB = wv::opaque(dcB);
+
       // bottom lines and modes for the row below (ring) or the band below (write-through)
       const unsigned m4 = [&]() {
         unsigned v = (unsigned)Mcur << (8 * (i & 3));
@@ -749,16 +869,17 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         const bool lineLane = i < 8 || i == 12;
         const int fo = i < 8 ? 4 * i : 32;
         if (valid && lineLane && g < 3 && g < gl) wv::lds_st32(ringBelow + RING_ENT * (x & 3) + fo, v);
-        const bool toGlobal = hasBelow && g == gl;
-        if (wv::any(valid && toGlobal)) {
-          if (valid && toGlobal && lineLane) {
-            unsigned* dst;
-            if (i < 4) dst = (unsigned*)(planeY + (size_t)(16 * r + 15) * pitchY + 16 * x + 4 * i);
-            else if (i < 8) dst = (unsigned*)(planeY + (i < 6 ? offCb : offCr) + (size_t)(8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
-            else dst = A.rowModes + (mbFrame + (unsigned)(r * W + x));
-            wv::st_sc1(dst, v);
+        if (hasBelow && wv::any(valid && g == gl)) {  // the band's last row: written through for the band below
+          if (valid && g == gl && lineLane) {
+            if (i < 8) {
+              const unsigned off = i < 4 ? (unsigned)((16 * r + 15) * pitchY + 16 * x + 4 * i)
+                                         : (i < 6 ? offCb : offCr) + (unsigned)((8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
+              wv::st_sc1((unsigned*)(planeY + off), v);
+            } else {
+              wv::st_sc1((unsigned*)(modesF + 4u * (unsigned)(r * W + x)), v);
+            }
           }
-          nSt++;
+          linePend = true;
         }
       }
       // left neighbour copies: luma column 15 (also the tile's x = -1 border when the next macroblock is slot 0)
@@ -772,6 +893,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       }
       Mprev = valid ? Mcur : 2;
       wv::wave_sync();
+      PH(12);  // lines, left copies
       // flush the staged rows: every second macroblock, or at the end of a row. 32 (luma) / 16 (chroma) contiguous
       // bytes per pixel row. The bottom lines of a band that has a band below were already written through.
       {
@@ -786,31 +908,38 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
                             !(hasBelow && fg == gl && fy == 15);
             const int src = ws + S_TILE + TILE_BYTES * fg + TILE_STRIDE * (fy + 1) + 8 + 16 * half;
             const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
-            if (ok) wv::st_g128(planeY + (size_t)(16 * (r0 + fg) + fy) * pitchY + 16 * (xp + half), u32x4{lo.x, lo.y, hi.x, hi.y});
+            if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + half)), u32x4{lo.x, lo.y, hi.x, hi.y});
           }
           {
             const int fg = lane >> 4, pl = (lane >> 3) & 1, fy = lane & 7;
             const int fx = s - 2 * fg, xp = fx & ~1;
             const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && !(hasBelow && fg == gl && fy == 7);
             const u32x4 v = wv::lds_u128(ws + S_STC + 256 * fg + 128 * pl + 16 * fy);
-            uint8_t* dst = planeY + (pl ? offCr : offCb) + (size_t)(8 * (r0 + fg) + fy) * pitchC + 8 * xp;
+            uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp));
             if (ok) {
               if (xp + 1 <= fx) wv::st_g128(dst, v);
               else wv::st_g64(dst, u32x2{v.x, v.y});
             }
           }
-          nSt += 4;
         }
       }
-      nStPrev = nSt;
       wv::wave_sync();
+      PH(13);  // flush
+      TRACE(5, s + 1);
     }
     // the band is complete once its last stores have been written through
     if (hasBelow) {
       wv::wait_vm(0);
       if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
     }
+    TRACE(6, task + 1u);
+    PH(14);  // band tail
   }
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  TRACE(7, 0xD0E);
+  if (lane0 == 0 && A.profile)
+    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
+#endif
 }
 
 }  // namespace band

@@ -39,6 +39,14 @@ struct dryv_recon_ctx {
   int grid_override = 0;
   bool use_df = false;  // dual-frame kernel (DRYV_RECON_DF=1)
   int kernel_sel = -1;  // DRYV_RECON_KERNEL: 0 row kernel, 1 band kernel, -1 default
+  // the launch in flight, kept so that a batch the fast band kernel flagged (status bit 1: a block beyond int32)
+  // can be run again with the wide build before its status is reported
+  KParams last_P;
+  const void* last_mbs = nullptr;
+  const void* last_coeffs = nullptr;
+  void* last_yuv = nullptr;
+  bool last_band = false;
+  int wide_reruns = 0;
   std::string last_error;
 };
 
@@ -63,33 +71,77 @@ int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
   return DRYV_OK;
 }
 
+size_t workspace_bytes(const KParams& P) {
+  size_t b = dryv::recon_workspace_bytes(P.W, P.H, P.n_frames);
+#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
+  b = dryv::band_profile_offset(P) + (size_t)65536 * 16 * 8 + (size_t)65536 * 32;
+#endif
+  return b;
+}
+
+int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, bool wide) {
+  hipError_t e;
+  const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
+  const int wpb = dryv::band_waves_per_block();
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
+  if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
+  if (grid < 1) grid = 1;
+  e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
+  e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_profile_offset(P), 0, (size_t)65536 * 16 * 8 + (size_t)65536 * 32, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(profile)");
+#endif
+  e = hipEventRecord(ctx->ev_start, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "band_kernel launch");
+  e = hipEventRecord(ctx->ev_stop, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemcpyAsync(status)");
+  ctx->timed = true;
+  return DRYV_OK;
+}
+
+// Waits for the launch in flight. A batch the fast band kernel flagged as needing 64-bit arithmetic is run again with
+// the wide build (same buffers; the caller's inputs are still valid: they must be until wait/sync returns).
+int finish(dryv_recon_ctx* ctx) {
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
+  if (ctx->last_band && (*ctx->h_status & 2u)) {
+    ctx->wide_reruns++;
+    e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
+    int st = launch_band(ctx, ctx->last_P, ctx->last_mbs, ctx->last_coeffs, ctx->last_yuv, true);
+    if (st != DRYV_OK) return st;
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
+  }
+  if (ctx->last_band && (*ctx->h_status & 4u)) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "band kernel: band task %u gave up waiting at step %u for the band above (needs %u macroblocks, saw %u)",
+             ctx->h_status[1], ctx->h_status[2] >> 16, ctx->h_status[2] & 0xffffu, ctx->h_status[3]);
+    ctx->last_error = msg;
+    return DRYV_E_DEVICE;
+  }
+  return DRYV_OK;
+}
+
 int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv) {
-  int st = ensure(ctx, &ctx->d_work, &ctx->cap_work, dryv::recon_workspace_bytes(P.W, P.H, P.n_frames));
+  int st = ensure(ctx, &ctx->d_work, &ctx->cap_work, workspace_bytes(P));
   if (st != DRYV_OK) return st;
   hipError_t e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
   // Persistent grid: 32 waves per CU (8 per SIMD at 64 VGPRs); each band slot of a workgroup keeps claiming 4-row
   // bands until none are left, so a smaller grid is merely slower and never incorrect.
   const bool band = ctx->kernel_sel == 1 || (ctx->kernel_sel < 0 && !P.transform8x8);
-  if (band) {
-    const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
-    const int wpb = dryv::band_waves_per_block();
-    long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
-    if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
-    if (grid < 1) grid = 1;
-    e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
-    e = hipEventRecord(ctx->ev_start, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-    e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, e, "band_kernel launch");
-    e = hipEventRecord(ctx->ev_stop, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-    e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, e, "hipMemcpyAsync(status)");
-    ctx->timed = true;
-    return DRYV_OK;
-  }
+  ctx->last_P = P;
+  ctx->last_mbs = d_mbs;
+  ctx->last_coeffs = d_coeffs;
+  ctx->last_yuv = d_yuv;
+  ctx->last_band = band;
+  if (band) return launch_band(ctx, P, d_mbs, d_coeffs, d_yuv, false);
   const int bpb = dryv::recon_bands_per_block();
   const bool df = ctx->use_df;
   const long long total_bands = df ? dryv::recon_task_count_df(P.H, P.n_frames) : (long long)P.n_frames * ((P.H + 3) / 4);
@@ -201,13 +253,17 @@ int dryv_recon_wait(dryv_recon_ctx* ctx, uint8_t* yuv_out, size_t yuv_out_bytes)
   if (!ctx->in_flight || !ctx->in_flight_host) return DRYV_E_STATE;
   if (yuv_out_bytes < ctx->pending_yuv_bytes) return DRYV_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  hipError_t e = hipMemcpyAsync(yuv_out, ctx->d_yuv, ctx->pending_yuv_bytes, hipMemcpyDeviceToHost, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "D2H planes");
-  e = hipStreamSynchronize(ctx->stream);
+  int st = finish(ctx);
+  hipError_t e = hipSuccess;
+  if (st == DRYV_OK) {
+    e = hipMemcpyAsync(yuv_out, ctx->d_yuv, ctx->pending_yuv_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
   ctx->in_flight = false;
   ctx->in_flight_host = false;
-  if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
-  return *ctx->h_status ? DRYV_E_UNSUPPORTED : DRYV_OK;
+  if (st != DRYV_OK) return st;
+  if (e != hipSuccess) return fail(ctx, e, "D2H planes");
+  return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;
 }
 
 int dryv_recon_submit_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const void* d_mbs,
@@ -229,10 +285,14 @@ int dryv_recon_submit_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, u
 int dryv_recon_sync(dryv_recon_ctx* ctx) {
   if (!ctx) return DRYV_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (!ctx->in_flight) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    return e == hipSuccess ? DRYV_OK : fail(ctx, e, "hipStreamSynchronize");
+  }
+  const int st = finish(ctx);
   if (!ctx->in_flight_host) ctx->in_flight = false;
-  if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
-  return *ctx->h_status ? DRYV_E_UNSUPPORTED : DRYV_OK;
+  if (st != DRYV_OK) return st;
+  return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;
 }
 
 int dryv_recon_last_kernel_ms(dryv_recon_ctx* ctx, float* ms) {
@@ -270,6 +330,28 @@ int dryv_recon_debug_phases(dryv_recon_ctx* ctx, const dryv_frame_params* fp, ui
   const size_t prog = (((size_t)n_frames * fp->pic_height_in_mbs * 4) + 255) & ~(size_t)255;
   const size_t off = ((256 + prog + (size_t)n_frames * fp->pic_width_in_mbs * fp->pic_height_in_mbs * 4) + 255) & ~(size_t)255;
   hipError_t e = hipMemcpy(out, (unsigned char*)ctx->d_work + off, (size_t)n_waves * 80, hipMemcpyDeviceToHost);
+  return e == hipSuccess ? DRYV_OK : DRYV_E_DEVICE;
+}
+#endif
+
+#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
+/* diagnostic build only: reads n_waves x 8 trace words and `n_prog` progress words while the kernel may still be running
+   (own stream) */
+int dryv_recon_debug_band_trace(dryv_recon_ctx* ctx, int n_waves, unsigned* out, int n_prog, unsigned* prog_out) {
+  if (!ctx || !out || n_waves > 65536 || !ctx->d_work) return DRYV_E_INVALID;
+  static hipStream_t s2 = nullptr;
+  if (!s2 && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return DRYV_E_DEVICE;
+  hipError_t e = hipMemcpyAsync(out, (unsigned char*)ctx->d_work + dryv::band_profile_offset(ctx->last_P) + (size_t)65536 * 16 * 8,
+                                (size_t)n_waves * 32, hipMemcpyDeviceToHost, s2);
+  if (e == hipSuccess && n_prog > 0) e = hipMemcpyAsync(prog_out, (unsigned char*)ctx->d_work + 256, (size_t)n_prog * 4, hipMemcpyDeviceToHost, s2);
+  if (e == hipSuccess) e = hipStreamSynchronize(s2);
+  return e == hipSuccess ? DRYV_OK : DRYV_E_DEVICE;
+}
+/* diagnostic build only: copies the per-wave phase cycle sums of the last band-kernel launch (n_waves x 16 u64) */
+int dryv_recon_debug_band_phases(dryv_recon_ctx* ctx, int n_waves, unsigned long long* out) {
+  if (!ctx || !out || n_waves > 65536 || !ctx->d_work) return DRYV_E_INVALID;
+  hipError_t e = hipMemcpy(out, (unsigned char*)ctx->d_work + dryv::band_profile_offset(ctx->last_P), (size_t)n_waves * 16 * 8,
+                           hipMemcpyDeviceToHost);
   return e == hipSuccess ? DRYV_OK : DRYV_E_DEVICE;
 }
 #endif

@@ -24,8 +24,9 @@ hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeff
 size_t band_lds_bytes(bool hasI8);
 int band_waves_per_block();
 int band_blocks_per_cu();
+size_t band_profile_offset(const KParams& P);  // DRYV_BAND_PROFILE builds: per-wave phase sums behind the workspace
 hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                       void* d_workspace, int grid, hipStream_t stream);
+                       void* d_workspace, int grid, bool wide, hipStream_t stream);
 
 // Dual-frame kernel (each wave works on the same row of two frames): 8-wave workgroups at 4 waves per SIMD.
 long long recon_task_count_df(int H, int n_frames);

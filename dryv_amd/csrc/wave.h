@@ -83,7 +83,7 @@ WV unsigned alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_a
 // ---- global memory ------------------------------------------------------------------------------------
 WV unsigned ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV void st_sc1(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-WV unsigned atomic_inc_task(unsigned* p) { return atomicAdd(p, 1u); }
+WV unsigned atomic_add_task(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 WV void atomic_or(unsigned* p, unsigned v) { atomicOr(p, v); }
 struct __attribute__((packed, aligned(2))) U128a2 { u32x4 v; };
 WV u32x4 ld_u128_a2(const void* p) { return ((const U128a2*)p)->v; }  // 2-byte-aligned 16-byte load (global_load_dwordx4)
@@ -91,7 +91,7 @@ struct __attribute__((packed, aligned(4))) U128a4 { u32x4 v; };
 struct __attribute__((packed, aligned(4))) U64a4 { u32x2 v; };
 WV void st_g128(void* p, u32x4 v) { ((U128a4*)p)->v = v; }  // dword-aligned 16-byte store (global_store_dwordx4)
 WV void st_g64(void* p, u32x2 v) { ((U64a4*)p)->v = v; }
-// all but the n youngest vector-memory operations of this wave have completed (n wave-uniform, 0..7)
+// all but the n youngest vector-memory operations of this wave have completed (n wave-uniform, 0..8)
 WV void wait_vm(int n) {
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -101,10 +101,14 @@ WV void wait_vm(int n) {
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
   }
 }
-WV void sleep_short() { __builtin_amdgcn_s_sleep(4); }
+#ifndef DRYV_BAND_SLEEP
+#define DRYV_BAND_SLEEP 4  // s_sleep argument (x64 clocks) between two polls of a progress word
+#endif
+WV void sleep_short() { __builtin_amdgcn_s_sleep(DRYV_BAND_SLEEP); }
 WV void sleep_long() { __builtin_amdgcn_s_sleep(32); }
 WV void compiler_fence() { asm volatile("" ::: "memory"); }
 // the value, behind a barrier the optimiser cannot see through: what is derived from it is recomputed, not kept live
@@ -130,7 +134,8 @@ struct EmuState {
   const char* tag[64];
   uint8_t lds[163840];
 };
-extern EmuState g_emu;
+extern EmuState* g_emu_cur;  // the wave that is running (several waves are interleaved: see band_emu.cpp)
+#define g_emu (*g_emu_cur)
 void emu_barrier(const char* tag);  // yields to the scheduler; returns once all 64 lanes arrived with the same tag
 
 WV int lane_id() { return g_emu.cur_lane; }
@@ -239,15 +244,15 @@ WV unsigned alignbit(unsigned hi, unsigned lo, unsigned sh) {
 
 WV unsigned ld_sc1(const unsigned* p) { return *(const volatile unsigned*)p; }
 WV void st_sc1(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
-WV unsigned atomic_inc_task(unsigned* p) { return (*p)++; }
+WV unsigned atomic_add_task(unsigned* p, unsigned v) { const unsigned o = *p; *p += v; return o; }
 WV void atomic_or(unsigned* p, unsigned v) { *p |= v; }
 WV u32x4 ld_u128_a2(const void* p) { u32x4 v; memcpy(&v, p, 16); return v; }
 WV void st_g128(void* p, u32x4 v) { memcpy(p, &v, 16); }
 WV void st_g64(void* p, u32x2 v) { memcpy(p, &v, 8); }
 WV void wait_vm(int) {}
-void emu_spin(const char* what);  // a spin-wait that cannot be satisfied in the sequential emulation: abort
-WV void sleep_short() { emu_spin("sleep_short"); }
-WV void sleep_long() { emu_spin("sleep_long"); }
+// a poll that failed: the wave yields to the other emulated waves (all 64 lanes get here together)
+WV void sleep_short() { emu_barrier("@sleep"); }
+WV void sleep_long() { emu_barrier("@sleep"); }
 WV void compiler_fence() {}
 WV int opaque(int v) { return v; }
 

@@ -2,96 +2,153 @@
 //
 // Compiles the band kernel's source with -DDRYV_EMU: every lane of a wavefront is a ucontext fiber, cross-lane
 // operations (DPP, ds_bpermute, readlane, ballot, wave barriers) meet at a fiber barrier that also checks that all
-// 64 lanes execute the same operation. One wave processes every band task in queue order, so inter-band
-// dependencies are always already satisfied. Used by tests/test_band_emu.py to check the kernel's index and
-// schedule logic against the oracle without a GPU; timing, memory ordering and inline asm are out of its reach.
+// 64 lanes execute the same operation. Several waves run interleaved: a wave runs until it polls a progress word in
+// vain (its s_sleep) or finishes, then the next wave gets the processor -- so the inter-band hand-off protocol
+// (claim order, progress words, deferred write-through) is exercised with real concurrency and a deadlock shows up
+// as "no wave can make progress". Used by tests/test_band_emu.py to check the kernel's logic against the oracle
+// without a GPU; timing, memory ordering and inline asm are out of its reach.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
 
+#include <algorithm>
+#include <memory>
 #include <vector>
 
 #include "../../dryv_amd/csrc/band_kernel.h"
 #include "../../dryv_amd/csrc/recon_params.h"
 
 namespace wv {
-EmuState g_emu;
-static ucontext_t g_sched, g_fiber[64];
-static int g_state[64];  // 0 runnable, 1 at barrier, 2 done
+EmuState* g_emu_cur = nullptr;
+
+struct Wave {
+  EmuState st;
+  ucontext_t fiber[64];
+  int state[64];  // 0 runnable, 1 at barrier, 2 done
+  std::vector<char> stacks;
+  bool finished = false;
+  unsigned long long slices = 0;
+};
+static Wave* g_wave = nullptr;
+static ucontext_t g_sched;
 static void (*g_body)();
 
 void emu_barrier(const char* tag) {
   const int l = g_emu.cur_lane;
   g_emu.tag[l] = tag;
-  g_state[l] = 1;
-  swapcontext(&g_fiber[l], &g_sched);
-}
-void emu_spin(const char* what) {
-  fprintf(stderr, "emu: lane %d would spin (%s): a dependency is not satisfied in queue order\n", g_emu.cur_lane, what);
-  abort();
+  g_wave->state[l] = 1;
+  swapcontext(&g_wave->fiber[l], &g_sched);
 }
 static void trampoline() {
   g_body();
-  g_state[g_emu.cur_lane] = 2;
-  swapcontext(&g_fiber[g_emu.cur_lane], &g_sched);
+  Wave* w = g_wave;
+  w->state[w->st.cur_lane] = 2;
+  swapcontext(&w->fiber[w->st.cur_lane], &g_sched);
 }
-static void run_wave(void (*body)()) {
-  static std::vector<char> stacks;
-  const size_t SS = 512 * 1024;
-  stacks.resize(64 * SS);
-  g_body = body;
+static void init_wave(Wave* w) {
+  const size_t SS = 384 * 1024;
+  w->stacks.resize(64 * SS);
+  memset(w->st.lds, 0xA5, sizeof(w->st.lds));
   for (int l = 0; l < 64; l++) {
-    getcontext(&g_fiber[l]);
-    g_fiber[l].uc_stack.ss_sp = stacks.data() + l * SS;
-    g_fiber[l].uc_stack.ss_size = SS;
-    g_fiber[l].uc_link = &g_sched;
-    makecontext(&g_fiber[l], trampoline, 0);
-    g_state[l] = 0;
+    getcontext(&w->fiber[l]);
+    w->fiber[l].uc_stack.ss_sp = w->stacks.data() + l * SS;
+    w->fiber[l].uc_stack.ss_size = SS;
+    w->fiber[l].uc_link = &g_sched;
+    makecontext(&w->fiber[l], trampoline, 0);
+    w->state[l] = 0;
   }
+}
+// runs wave w until it finishes (returns 2), or until all its lanes sit in a failed poll (returns 1)
+static int run_slice(Wave* w) {
+  g_wave = w;
+  g_emu_cur = &w->st;
   for (;;) {
     int done = 0, waiting = 0;
     for (int l = 0; l < 64; l++) {
-      if (g_state[l] == 2) { done++; continue; }
-      g_emu.cur_lane = l;
-      g_state[l] = 0;
-      swapcontext(&g_sched, &g_fiber[l]);
-      if (g_state[l] == 2) done++;
+      if (w->state[l] == 2) { done++; continue; }
+      w->st.cur_lane = l;
+      w->state[l] = 0;
+      swapcontext(&g_sched, &w->fiber[l]);
+      if (w->state[l] == 2) done++;
       else waiting++;
     }
-    if (done == 64) return;
+    if (done == 64) { w->finished = true; return 2; }
     if (done != 0) {
       fprintf(stderr, "emu: %d lanes finished while %d wait at a cross-lane operation (divergent control flow)\n", done, waiting);
       abort();
     }
     for (int l = 1; l < 64; l++)
-      if (strcmp(g_emu.tag[l], g_emu.tag[0]) != 0) {
-        fprintf(stderr, "emu: lane %d is at '%s' while lane 0 is at '%s' (divergent cross-lane operation)\n", l, g_emu.tag[l], g_emu.tag[0]);
+      if (strcmp(w->st.tag[l], w->st.tag[0]) != 0) {
+        fprintf(stderr, "emu: lane %d is at '%s' while lane 0 is at '%s' (divergent cross-lane operation)\n", l, w->st.tag[l], w->st.tag[0]);
         abort();
       }
+    if (w->st.tag[0][0] == '@') return 1;  // a poll failed: let the other waves run
   }
 }
 }  // namespace wv
 
 static dryv::KParams g_P;
 static dryv::band::Args g_A;
+static bool g_wide;
 static void body() {
-  if (g_P.transform8x8) dryv::band::band_wave<true>(g_P, g_A, 0, dryv::band::T_END_I8);
-  else dryv::band::band_wave<false>(g_P, g_A, 0, dryv::band::T_END);
+  if (g_wide) {
+    if (g_P.transform8x8) dryv::band::band_wave<true, true>(g_P, g_A, 0, dryv::band::T_END_I8);
+    else dryv::band::band_wave<false, true>(g_P, g_A, 0, dryv::band::T_END);
+  } else {
+    if (g_P.transform8x8) dryv::band::band_wave<true, false>(g_P, g_A, 0, dryv::band::T_END_I8);
+    else dryv::band::band_wave<false, false>(g_P, g_A, 0, dryv::band::T_END);
+  }
 }
 
+// n_waves = 1: one wave takes every band in queue order (dependencies always already satisfied).
+// n_waves > 1: that many waves claim bands concurrently, scheduled round-robin from wave `first`, `order` = +1 / -1.
 extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_frames, const dryv_mb_desc* mbs,
-                                    const int16_t* coeffs, uint8_t* yuv, unsigned* status_out) {
+                                    const int16_t* coeffs, uint8_t* yuv, unsigned* status_out, int n_waves, int first,
+                                    int order) {
   int st = dryv::params::build_params(fp, n_frames, &g_P);
   if (st != DRYV_OK) return st;
+  if (n_waves < 1) n_waves = 1;
   const int nBands = (g_P.H + 3) / 4;
   std::vector<unsigned> prog((size_t)n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H, 0xEEEEEEEEu);
-  unsigned counter = 0, status = 0;
-  g_A = dryv::band::Args{mbs, coeffs, yuv, &status, prog.data(), modes.data(), &counter};
-  memset(wv::g_emu.lds, 0xA5, sizeof(wv::g_emu.lds));
-  dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
-  wv::run_wave(body);
-  if (status_out) *status_out = status;
+  // like the host API: the fast build first; if it flags a block beyond int32 (status bit 1), the batch again with the wide build
+  unsigned status[4] = {0, 0, 0, 0};
+  for (int pass = 0; pass < 2; pass++) {
+    unsigned counter = 0;
+    memset(status, 0, sizeof status);
+    std::fill(prog.begin(), prog.end(), 0u);
+    g_wide = pass == 1;
+    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), modes.data(), &counter, nullptr, 0};
+    wv::g_body = body;
+    std::vector<std::unique_ptr<wv::Wave>> waves;
+    for (int w = 0; w < n_waves; w++) {
+      waves.emplace_back(new wv::Wave());
+      wv::init_wave(waves.back().get());
+      wv::g_emu_cur = &waves.back()->st;
+      dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
+    }
+    int live = n_waves;
+    unsigned long long idle_rounds = 0;
+    for (int k = 0; live > 0; k++) {
+      wv::Wave* w = waves[(((first + order * k) % n_waves) + n_waves) % n_waves].get();
+      if (w->finished) continue;
+      const unsigned before = counter;
+      unsigned long long sum0 = 0;
+      for (unsigned v : prog) sum0 += v;
+      const int r = wv::run_slice(w);
+      if (r == 2) live--;
+      unsigned long long sum1 = 0;
+      for (unsigned v : prog) sum1 += v;
+      if (r == 2 || counter != before || sum1 != sum0) idle_rounds = 0;
+      else if (++idle_rounds > (unsigned long long)n_waves * 64) {
+        fprintf(stderr, "emu: deadlock: %d waves are polling and nothing makes progress\n", live);
+        abort();
+      }
+    }
+    if (!(status[0] & 2u)) break;
+    if (getenv("DRYV_EMU_VERBOSE")) fprintf(stderr, "emu: batch flagged for the wide build\n");
+  }
+  if (status_out) *status_out = status[0] & ~2u;
   return DRYV_OK;
 }

@@ -24,12 +24,13 @@ def build(force=False):
     return SO
 
 
-def reconstruct(fp, n_frames, mbs, coeffs):
+def reconstruct(fp, n_frames, mbs, coeffs, n_waves=1, first=0, order=1):
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.dryv_emu_reconstruct.restype = C.c_int
-        _lib.dryv_emu_reconstruct.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.dryv_emu_reconstruct.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_int]
     mbs = np.ascontiguousarray(mbs)
     coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
     n_mbs = n_frames * fp.pic_width_in_mbs * fp.pic_height_in_mbs
@@ -37,6 +38,6 @@ def reconstruct(fp, n_frames, mbs, coeffs):
     yuv = np.zeros(n_mbs * 384, dtype=np.uint8)
     status = C.c_uint(0)
     st = _lib.dryv_emu_reconstruct(C.addressof(fp), n_frames, mbs.ctypes.data, coeffs.ctypes.data, yuv.ctypes.data,
-                                   C.addressof(status))
+                                   C.addressof(status), n_waves, first, order)
     assert st == 0, st
     return int(status.value), yuv

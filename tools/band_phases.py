@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a band wave spend its cycles?
+
+Builds libdryv_recon_bprof.so with -DDRYV_BAND_PROFILE (s_memtime stamps around each phase of the band kernel's step,
+summed per wave into a buffer of their own), runs the C2 workload with the given numbers of frames and prints cycles
+per step and phase. The stamps drain the LDS queue and fence overlaps the real kernel has: read shares, not run time
+(cdna_hip_programming.md section 7). Never used by tests, bench or the product.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dryv_amd import _build, abi, synth  # noqa: E402
+
+PHASES = ["claim+prologue", "publish", "record decode", "luma residuals", "hand-off+prefetch", "res store+top border",
+          "modes", "intra16x16", "chroma residuals", "chroma pred", "top-right copy", "intra4x4 chain",
+          "lines+left copies", "flush", "band tail", "-"]
+
+
+def main():
+    frame_list = [int(a) for a in sys.argv[1:]] or [1, 300]
+    so = os.path.join(_build.LIB, "libdryv_recon_bprof.so")
+    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "recon_api.hip")]
+    subprocess.check_call([_build.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-DDRYV_BAND_PROFILE", "-o", so] + srcs)
+    import torch
+    lib = abi.load_library(so)
+    lib.dryv_recon_debug_band_phases.restype = C.c_int
+    for frames in frame_list:
+        fp, mbs, co, n = synth.workload("C2_1080p_intra_4x4", n_frames=frames)
+        d_m = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda()
+        d_c = torch.from_numpy(co).cuda()
+        d_o = torch.zeros(mbs.size * 384, dtype=torch.uint8, device="cuda")
+        h = C.c_void_p()
+        assert lib.dryv_recon_create(C.byref(h), 0) == 0
+        for _ in range(4):
+            assert lib.dryv_recon_submit_device(h, C.byref(fp), n, C.c_void_p(d_m.data_ptr()), C.c_void_p(d_c.data_ptr()),
+                                                C.c_void_p(d_o.data_ptr())) == 0
+            assert lib.dryv_recon_sync(h) == 0
+        ms = C.c_float()
+        lib.dryv_recon_last_kernel_ms(h, C.byref(ms))
+        tasks = n * 17
+        n_waves = min(5120, (tasks + 4) // 5 * 5)
+        out = np.zeros((n_waves, 16), dtype=np.uint64)
+        assert lib.dryv_recon_debug_band_phases(h, C.c_int(n_waves), out.ctypes.data_as(C.c_void_p)) == 0
+        tot = out.sum(axis=0).astype(np.float64)
+        steps = tasks * 126.0
+        print("== %d frames: instrumented kernel %.3f ms, %d waves, %d band tasks" % (frames, ms.value, n_waves, tasks))
+        for name, v in zip(PHASES, tot):
+            if v > 0:
+                print("  %-24s %6.2f %%   %8.0f cycles/step" % (name, 100 * v / tot.sum(), v / steps))
+        print("  total %.0f wave-cycles/step (%.0f per macroblock)" % (tot.sum() / steps, tot.sum() / mbs.size))
+        lib.dryv_recon_destroy(h)
+        del d_m, d_c, d_o
+
+
+if __name__ == "__main__":
+    main()
