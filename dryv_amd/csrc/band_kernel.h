@@ -473,9 +473,9 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       }
       PH(3);  // luma residuals
       // ---- hand-off traffic, placed here so that nothing in front of the residuals waits for it.
-      // Publish: the previous step ended with the write-through stores of its last-row macroblock's bottom lines (and
-      // the staged row segments). By now they have had a residual pass to drain; once vmcnt says so (everything this
-      // wave has issued is done: loads and stores count together, in order) the macroblock is published.
+      // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom lines (and
+      // the staged row segments). They have had a residual pass to drain; once vmcnt says that everything this wave has
+      // issued is done (loads and stores count together, in order) the macroblock is published.
       if (linePend) {
         wv::wait_vm(0);
         const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
@@ -845,13 +845,15 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       // ================= write-out ================================================================================
       // The prefetched record and coefficients are "used" here, in front of this step's stores: the compiler then
       // waits for those loads now (they were issued thousands of cycles ago) instead of at the top of the next step,
-      // where its vmcnt(0) would also wait for the stores below.
+      // where its vmcnt(0) would also wait for the stores below -- and a write-through store takes thousands of cycles
+      // to be acknowledged when the chip is busy. (Measured alternative, not kept: a constant number of stores per step,
+      // padded with stores to a dump area, so that the compiler could count them: its waits stayed vmcnt(0) across the
+      // loop back-edge and the batch took 2.67 ms instead of 2.45.)
       dN1.x = (unsigned)wv::opaque((int)dN1.x); dN1.y = (unsigned)wv::opaque((int)dN1.y);
       dN1.z = (unsigned)wv::opaque((int)dN1.z); dN1.w = (unsigned)wv::opaque((int)dN1.w);
       kN2 = (unsigned)wv::opaque((int)kN2);
       cA0.x = (unsigned)wv::opaque((int)cA0.x); cA1.x = (unsigned)wv::opaque((int)cA1.x); dcA = wv::opaque(dcA);
       cB0.x = (unsigned)wv::opaque((int)cB0.x); cB1.x = (unsigned)wv::opaque((int)cB1.x); dcB = wv::opaque(dcB);
-
       // bottom lines and modes for the row below (ring) or the band below (write-through)
       const unsigned m4 = [&]() {
         unsigned v = (unsigned)Mcur << (8 * (i & 3));
@@ -896,30 +898,27 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       PH(12);  // lines, left copies
       // flush the staged rows: every second macroblock, or at the end of a row. 32 (luma) / 16 (chroma) contiguous
       // bytes per pixel row. The bottom lines of a band that has a band below were already written through.
-      {
-        const bool flushMine = valid && (slot == 1 || x == W - 1);
-        if (wv::any(flushMine)) {
+      if (wv::any(valid && (slot == 1 || x == W - 1))) {
 #pragma unroll
-          for (int it = 0; it < 2; it++) {
-            const int q = lane + 64 * it;
-            const int fg = q >> 5, fy = (q >> 1) & 15, half = q & 1;
-            const int fx = s - 2 * fg, xp = fx & ~1;
-            const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && xp + half <= fx &&
-                            !(hasBelow && fg == gl && fy == 15);
-            const int src = ws + S_TILE + TILE_BYTES * fg + TILE_STRIDE * (fy + 1) + 8 + 16 * half;
-            const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
-            if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + half)), u32x4{lo.x, lo.y, hi.x, hi.y});
-          }
-          {
-            const int fg = lane >> 4, pl = (lane >> 3) & 1, fy = lane & 7;
-            const int fx = s - 2 * fg, xp = fx & ~1;
-            const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && !(hasBelow && fg == gl && fy == 7);
-            const u32x4 v = wv::lds_u128(ws + S_STC + 256 * fg + 128 * pl + 16 * fy);
-            uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp));
-            if (ok) {
-              if (xp + 1 <= fx) wv::st_g128(dst, v);
-              else wv::st_g64(dst, u32x2{v.x, v.y});
-            }
+        for (int it = 0; it < 2; it++) {
+          const int q = lane + 64 * it;
+          const int fg = q >> 5, fy = (q >> 1) & 15, half = q & 1;
+          const int fx = s - 2 * fg, xp = fx & ~1;
+          const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && xp + half <= fx &&
+                          !(hasBelow && fg == gl && fy == 15);
+          const int src = ws + S_TILE + TILE_BYTES * fg + TILE_STRIDE * (fy + 1) + 8 + 16 * half;
+          const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
+          if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + half)), u32x4{lo.x, lo.y, hi.x, hi.y});
+        }
+        {
+          const int fg = lane >> 4, pl = (lane >> 3) & 1, fy = lane & 7;
+          const int fx = s - 2 * fg, xp = fx & ~1;
+          const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && !(hasBelow && fg == gl && fy == 7);
+          const u32x4 v = wv::lds_u128(ws + S_STC + 256 * fg + 128 * pl + 16 * fy);
+          uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp));
+          if (ok) {
+            if (xp + 1 <= fx) wv::st_g128(dst, v);
+            else wv::st_g64(dst, u32x2{v.x, v.y});
           }
         }
       }

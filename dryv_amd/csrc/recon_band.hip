@@ -23,6 +23,7 @@ size_t band_lds_bytes(bool hasI8) { return (size_t)(hasI8 ? band::T_END_I8 : ban
 int band_waves_per_block() { return band::WAVES_PER_WG; }
 int band_blocks_per_cu() { return 4; }
 
+// Workspace: [task counter | pad to 256][progress words][bottom-row modes][diagnostics]
 size_t band_profile_offset(const KParams& P) {
   return ((256 + (((size_t)P.n_frames * P.H * 4) + 255) / 256 * 256 + (size_t)P.n_frames * P.W * P.H * 4) + 255) & ~(size_t)255;
 }

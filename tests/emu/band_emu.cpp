@@ -25,6 +25,7 @@ EmuState* g_emu_cur = nullptr;
 
 struct Wave {
   EmuState st;
+  int index = 0;
   ucontext_t fiber[64];
   int state[64];  // 0 runnable, 1 at barrier, 2 done
   std::vector<char> stacks;
@@ -92,6 +93,7 @@ static int run_slice(Wave* w) {
 static dryv::KParams g_P;
 static dryv::band::Args g_A;
 static bool g_wide;
+static int wave_index() { return wv::g_wave->index; }
 static void body() {
   if (g_wide) {
     if (g_P.transform8x8) dryv::band::band_wave<true, true>(g_P, g_A, 0, dryv::band::T_END_I8);
@@ -124,6 +126,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
     std::vector<std::unique_ptr<wv::Wave>> waves;
     for (int w = 0; w < n_waves; w++) {
       waves.emplace_back(new wv::Wave());
+      waves.back()->index = w;
       wv::init_wave(waves.back().get());
       wv::g_emu_cur = &waves.back()->st;
       dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
