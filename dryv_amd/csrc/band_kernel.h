@@ -1,28 +1,38 @@
-// band_kernel.h — macroblock reconstruction, one wavefront per BAND of four macroblock rows (gfx950).
+// band_kernel.h — macroblock reconstruction, one TEAM of two wavefronts per band of four macroblock rows (gfx950).
 //
 // Decomposition
-//   * The unit of work is a band: 4 consecutive macroblock rows of one frame. ONE 64-lane wave owns it; lanes
-//     16g..16g+15 belong to row g of the band. The rows advance in lockstep as a 2:1 diagonal: at step s row g
-//     works on macroblock x = s - 2g, so neighbours A, B, C, D of every macroblock (slice/mod.rs:576-613) were
-//     finished by the same wave one or two steps earlier -- no synchronisation inside a band at all.
+//   * The unit of work is a band: 4 consecutive macroblock rows of one frame. Lanes 16g..16g+15 of a wave belong to
+//     row g of the band. The rows advance in lockstep as a 2:1 diagonal: at step s row g works on macroblock
+//     x = s - 2g, so neighbours A, B, C, D of every macroblock (slice/mod.rs:576-613) were finished by the same wave
+//     one or two steps earlier -- no synchronisation between the rows of a band at all.
+//   * A band is worked on by two waves of one workgroup that run on different SIMDs:
+//       FRONT  record decode, all residuals (luma residuals go to a double-buffered LDS area), Intra4x4/8x8 mode
+//              derivation, and ALL of chroma (prediction, staging, stores, hand-off) -- nothing in it depends on a
+//              luma pixel;
+//       BACK   luma prediction (Intra16x16, the Intra4x4 block wavefront), luma staging, stores, hand-off.
+//     The only coupling is the per-step record FRONT leaves in LDS (residuals, table rows, macroblock kinds) and two
+//     LDS words per buffer (ready / free). A lone wave issues about one instruction every 4-5 cycles whatever its
+//     kind, so a step's latency is its instruction count; the split halves it, and with it the frame's critical
+//     path (a frame is a 2:1 wavefront of 120 + 2 x 67 macroblock steps that no amount of parallel frames shortens).
 //   * Bands come off one queue in band-major order (band 0 of every frame, band 1 of every frame, ...): a band's
 //     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running or done, so
-//     there is no deadlock at any residency. 300 frames x 17 bands = 5100 waves fit the chip at once (5 per SIMD).
+//     there is no deadlock at any residency.
 //   * Between bands the hand-off goes through L2 (MI355X_MICROARCH.md "valid forms", sc1 stores + drained flag,
-//     sc1 loads): the band's last row stores its bottom pixel lines and bottom-row modes write-through and, after
-//     the next step's luma residuals -- when s_waitcnt vmcnt(0) has shown those stores complete -- publishes its
-//     progress word. The band below reads that word one step ahead and fetches one macroblock's lines per step.
+//     sc1 loads), separately for luma (BACK: bottom pixel line) and chroma (FRONT: bottom lines + bottom-row
+//     modes): the band's last row stores them write-through and, a good part of a step later -- when s_waitcnt
+//     vmcnt(0) has shown those stores complete -- publishes its progress word. The band below reads that word one
+//     step ahead and fetches one macroblock's lines per step.
 //
 // Inside a step (4 macroblocks)
 //   * residual: ONE LANE PER 4x4 BLOCK. The lane loads its block's 16 coefficients (32 contiguous bytes of the
 //     reference's list order) straight into registers, so the inverse zig-zag is register renaming, both butterfly
-//     passes are in-lane, and no transpose or LDS traffic exists. Luma: 64 lanes = 4 MB x 16 blocks; chroma: 32
-//     lanes = 4 MB x 2 planes x 4 blocks. Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP.
+//     passes are in-lane, and no transpose exists. Luma: 64 lanes = 4 MB x 16 blocks; chroma: 32 lanes = 4 MB x
+//     2 planes x 4 blocks. Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP.
 //     int32 arithmetic with a per-qp coefficient bound (KParams::thr4). A block beyond it flags the batch, and the
 //     host re-runs the batch with the WIDE build of this kernel, whose passes switch to int64 (reference: isize)
 //     for such waves: the result is the reference's for every int16 input.
-//   * Intra16x16 and chroma prediction stay in the lane-per-block layout (residuals never leave registers): V, H
-//     and DC are one v_perm_b32 byte-select per pixel pair, plane is packed 16-bit arithmetic.
+//   * Intra16x16 and chroma prediction use the same lane-per-block layout: V, H and DC are one v_perm_b32
+//     byte-select per pixel pair, plane is packed 16-bit arithmetic.
 //   * Intra4x4: prediction modes by the 7-sweep DPP relaxation over the block grid (one DPP row per macroblock),
 //     pixels by a 10-step 2:1 block wavefront with 8 lanes per block (2 pixels each): every pixel is
 //     (E[p] + 2E[q] + E[r] + 2) >> 2 of three samples whose tile offsets come from a per-(mode, pixel) table.
@@ -47,22 +57,33 @@ constexpr int T_END = 1280;
 constexpr int T_LS8 = 1280;   // u16 [6][64]    (HAS_I8 only)
 constexpr int T_END_I8 = 2048;
 
-// ---- per-wave scratch in LDS (byte offsets from the wave's base) ---------------------------------------------
+// ---- per-team scratch in LDS (byte offsets from the team's base) ---------------------------------------------
 constexpr int TILE_STRIDE = 40;
 constexpr int TILE_BYTES = 704;  // 17 rows x 40 + 8 (row y = -1 of slot 1 reaches 8 bytes into row y = 0), 64-aligned
-constexpr int S_RES = 0;         // i16 [4][16 blk][16]  luma residual of Intra4x4 macroblocks, [blkIdx][y][x]
-constexpr int S_TILE = 2048;     // u8  [4][TILE_BYTES]  luma: row j = y + 1, column 8 + 16 * (x & 1) + xr
-constexpr int S_STC = S_TILE + 4 * TILE_BYTES;  // u8 [4][2][8][16] chroma staging, two macroblocks wide
-constexpr int S_RING = S_STC + 1024;            // [4][4][40] bottom lines of the row above: Y[16] Cb[8] Cr[8] modes
-constexpr int RING_ROW = 160, RING_ENT = 40;
-constexpr int S_LEFTY = S_RING + 640;           // u8 [4][16] column 15 of the macroblock to the left
-constexpr int S_LEFTC = S_LEFTY + 64;           // u8 [4][2][8]
-constexpr int S_MSEQ = S_LEFTC + 64;            // u8 [4][2][12] Intra4x4 table row per chain step and block half
-constexpr int S_BYTES = 6784;                   // (64-byte multiple)
-static_assert(S_MSEQ + 96 <= S_BYTES, "scratch layout");
+// FRONT -> BACK, double-buffered by the parity of the team's global step count
+constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [blkIdx][y][x]
+constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       Intra4x4 table row per chain step and block half
+constexpr int S_INFO = 4288;     // u32 [2][8]              kinds of the 4 macroblocks, Intra16x16 modes, task, step
+constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2]   (global step count + 1 of the record in / consumed from the buffer)
+// BACK
+constexpr int S_TILE = 4416;     // u8  [4][TILE_BYTES]  luma: row j = y + 1, column 8 + 16 * (x & 1) + xr
+constexpr int S_RINGY = S_TILE + 4 * TILE_BYTES;  // u8 [4][4][16]  bottom luma lines of the row above
+constexpr int S_LEFTY = S_RINGY + 256;            // u8 [4][16]     column 15 of the macroblock to the left
+// FRONT
+constexpr int S_STC = S_LEFTY + 64;               // u8 [4][2][8][16] chroma staging, two macroblocks wide
+constexpr int S_RINGC = S_STC + 1024;             // [4][4][24]  bottom chroma lines of the row above: Cb[8] Cr[8] modes
+constexpr int RINGC_ROW = 96, RINGC_ENT = 24;
+constexpr int S_LEFTC = S_RINGC + 384;            // u8 [4][2][8]
+constexpr int S_BYTES = 9088;                     // (64-byte multiple)
+static_assert(S_LEFTC + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 
-constexpr int WAVES_PER_WG = 5;
+#ifndef DRYV_BAND_TEAMS
+#define DRYV_BAND_TEAMS 4   // teams per workgroup (tools/band_variants.sh: 4 x 3 workgroups per CU measured best)
+#endif
+constexpr int TEAMS_PER_WG = DRYV_BAND_TEAMS;
+constexpr int WAVES_PER_WG = 2 * TEAMS_PER_WG;
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a progress word (about a second) before a band gives up
+constexpr unsigned TASK_END = 0xFFFFFFFFu;
 
 // Diagnostic builds only. -DDRYV_BAND_PROFILE (tools/band_phases.py): per-wave cycle sums per phase of the step.
 // -DDRYV_BAND_TRACE (tools/band_trace.py): breadcrumbs only. Both write to a buffer of their own; the shipped library
@@ -100,12 +121,14 @@ struct Args {
   const int16_t* coeffs;
   uint8_t* yuv;
   unsigned* status;
-  unsigned* bandProg;   // [frame][band]: macroblocks of the band's last row whose bottom lines are visible
+  unsigned* progY;      // [frame][band]: macroblocks of the band's last row whose bottom luma line is visible
+  unsigned* progC;      // [frame][band]: the same for its bottom chroma lines and bottom-row modes
   unsigned* rowModes;   // [mb]: bottom-row Intra4x4/8x8 modes (only rows that end a band are written)
   unsigned* taskCounter;
   unsigned long long* profile;  // DRYV_BAND_PROFILE builds only
   int waveBase;                 // (global index of the workgroup's first wave, for the same)
 };
+
 
 // zig-zag (frame/mod.rs:185-209): list index of matrix element (row, col)
 #define ZZ4IDX(r, c) ((int)((0xFEA9DB83C7426510ull >> (4 * ((r) * 4 + (c)))) & 15ull))
@@ -299,9 +322,59 @@ WV unsigned recon_row(unsigned p01, unsigned p23, unsigned r01, unsigned r23) {
   return (a & 0xffffu) | (b << 16);
 }
 
-// ---- the kernel body: one wave, any number of band tasks -----------------------------------------------------
+
+// ---- geometry of a band task (wave-uniform) ----------------------------------------------------------------------
+struct BandGeo {
+  int b, f, r0, nR, gl, nSteps;
+  bool hasAbove, hasBelow;
+};
+WV BandGeo band_geo(unsigned task, int nF, int W, int H) {
+  BandGeo G;
+  G.b = (int)(task / (unsigned)nF);
+  G.f = (int)(task - (unsigned)G.b * (unsigned)nF);
+  G.r0 = 4 * G.b;
+  G.nR = min(4, H - G.r0);
+  G.gl = G.nR - 1;  // the band's last row
+  G.nSteps = W + 2 * (G.nR - 1);
+  G.hasAbove = G.b > 0;
+  G.hasBelow = G.r0 + G.nR < H;
+  return G;
+}
+
+// Waits (polling LDS) until the team's flag word at `addr` equals `want`.
+WV void team_wait(int addr, unsigned want) {
+  while ((unsigned)wv::rfl((int)wv::lds_u32(addr)) != want) wv::sleep_team();
+}
+
+// Polls the progress word of the band above until it reaches `need` (bounded: see SPIN_LIMIT).
+WV unsigned poll_progress(const unsigned* prog, unsigned known, unsigned need, unsigned W, unsigned* status, unsigned task,
+                          int s, int lane) {
+  unsigned spins = 0;
+  while (known < need) {
+    const unsigned v = wv::ld_sc1(prog);  // (all lanes, one address: one request)
+    known = (unsigned)wv::rfl((int)v);
+    if (known < need) {
+      wv::sleep_short();
+      if (++spins > SPIN_LIMIT) {
+        // every spin is bounded: a band above that never gets there is reported (status bit 2 + where), not waited for
+        if (lane == 0) {
+          wv::atomic_or(status, 4u);
+          status[1] = task;
+          status[2] = ((unsigned)s << 16) | need;
+          status[3] = known;
+        }
+        known = W;
+      }
+    }
+  }
+  return known;
+}
+
+// ==================================================================================================================
+// FRONT wave: records, residuals, mode derivation, chroma
+// ==================================================================================================================
 template <bool HAS_I8, bool WIDE>
-WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int ws) {
+WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
   unsigned long long phAcc[BAND_NPH];
@@ -312,9 +385,10 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
   const int W = P.W, H = P.H, nF = P.n_frames;
   const int nBands = (H + 3) >> 2;
   const unsigned totalTasks = (unsigned)nF * (unsigned)nBands;
-  const int pitchY = W * 16, pitchC = W * 8;
+  const int pitchC = W * 8;
   const size_t frameBytes = (size_t)W * H * 384;
   const unsigned offCb = (unsigned)W * H * 256u, offCr = offCb + (unsigned)W * H * 64u;
+  unsigned gstep = 0;  // steps of this team so far, over all its tasks: buffer = parity, flags carry gstep + 1
 
   for (;;) {
     // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
@@ -322,21 +396,27 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
     // loop, after which the readfirstlane executes under a partial exec mask and returns another lane's value.
     const unsigned tsk = wv::atomic_add_task(A.taskCounter, lane0 == 0 ? 1u : 0u);
     const unsigned task = (unsigned)wv::rfl((int)tsk);
-    if (task >= totalTasks) break;
+    if (task >= totalTasks) {
+      // tell BACK to stop: an end record in the next buffer
+      const int buf = (int)(gstep & 1u);
+      if (gstep >= 2) team_wait(ts + S_FLAGS + 8 + 4 * buf, gstep - 1);
+      if (lane0 == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 16, TASK_END);
+      wv::wave_sync();
+      if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + 4 * buf, gstep + 1);
+      break;
+    }
     TRACE(0, task + 1u);
-    const int b = (int)(task / (unsigned)nF), f = (int)(task - (unsigned)b * (unsigned)nF);
-    const int r0 = 4 * b, nR = min(4, H - r0);
-    const bool hasAbove = b > 0, hasBelow = r0 + nR < H;
-    const int gl = nR - 1;  // the band's last row
-    const int nSteps = W + 2 * (nR - 1);
+    const BandGeo G = band_geo(task, nF, W, H);
+    const int r0 = G.r0, nR = G.nR, gl = G.gl, nSteps = G.nSteps;
+    const bool hasAbove = G.hasAbove, hasBelow = G.hasBelow;
     // per-frame bases (wave-uniform); everything below addresses them with 32-bit offsets: a frame's planes, records
     // and coefficients are each < 4 GB (the host API checks)
-    uint8_t* const planeY = A.yuv + (size_t)f * frameBytes;
-    const size_t mbFrame = (size_t)f * (size_t)(W * H);
+    uint8_t* const planeY = A.yuv + (size_t)G.f * frameBytes;
+    const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
     const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
     uint8_t* const modesF = (uint8_t*)(A.rowModes + mbFrame);
-    unsigned* const myProg = A.bandProg + (size_t)f * nBands + b;
+    unsigned* const myProg = A.progC + (size_t)G.f * nBands + G.b;
     const unsigned* const upProg = myProg - 1;
 
     // ---- software pipeline: a step's record is fetched one step ahead (its first word, which decides the
@@ -390,13 +470,14 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
 
     PH(0);  // claim, prologue loads
     int Mprev = 2;           // derived modes of the macroblock to the left on the raster block grid
-    unsigned upKnown = 0;    // what this wave knows of the band above's progress
+    unsigned upKnown = 0;    // what this wave knows of the band above's (chroma) progress
     unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
     bool flagPend = false;
     bool linePend = false;   // bottom lines of the band's last row were stored in the previous step, not yet published
 
-    for (int s = 0; s < nSteps; s++) {
+    for (int s = 0; s < nSteps; s++, gstep++) {
       TRACE(1, s + 1);
+      const int buf = (int)(gstep & 1u);
       const u32x4 dCur = dN1;
       const unsigned kN1 = kN2;  // first record word of step s+1
       // lane roles (see the pipeline comment above)
@@ -407,17 +488,13 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;           // chroma lane-per-block (lanes 0..31)
       const int ccx = cblk & 1, ccy = cblk >> 1;
       const bool chromaLane = lane < 32;
-      const int ch = (i >> 3) & 1, cp = i & 7;                                          // Intra4x4 chain: block half, pixel pair
-      const int tile = ws + S_TILE + TILE_BYTES * g;
-      const int ringMine = ws + S_RING + RING_ROW * g;         // lines of the row above row g
-      const int ringBelow = ws + S_RING + RING_ROW * (g + 1);  // where row g publishes for row g+1 (g < 3)
+      const int ringC = ts + S_RINGC + RINGC_ROW * g;   // chroma lines + modes of the row above row g (luma lane roles)
       const int r = r0 + g, rC = r0 + gc;
       const bool rowOk = g < nR, rowOkC = gc < nR;
       const bool mbB = r > 0, mbBC = rC > 0;
       const int x = s - 2 * g, xC = s - 2 * gc;
       const bool valid = rowOk && x >= 0 && x < W, validC = rowOkC && xC >= 0 && xC < W;
       const int slot = s & 1;  // (x & 1 for every row)
-
       const bool needUp = hasAbove && s < W;
       unsigned lineV = 0;
 
@@ -439,7 +516,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       const int kindC = (int)(dC & 0xffu), cmode = (int)((dC >> 16) & 0xffu), qpC = (int)(dC >> 24);
       const bool mbAC = xC > 0;
 
-      PH(2);  // record decode
+      PH(1);  // record decode
       // ================= residuals ================================================================================
       unsigned rA[8];
       {
@@ -471,11 +548,11 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
           for (int k = 0; k < 8; k++) rA[k] = 0;
         }
       }
-      PH(3);  // luma residuals
+      PH(2);  // luma residuals
       // ---- hand-off traffic, placed here so that nothing in front of the residuals waits for it.
-      // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom lines (and
-      // the staged row segments). They have had a residual pass to drain; once vmcnt says that everything this wave has
-      // issued is done (loads and stores count together, in order) the macroblock is published.
+      // Publish: the previous step ended with the write-through stores of its last-row macroblock's bottom chroma lines
+      // and modes (and the staged row segments). They have had a residual pass to drain; once vmcnt says that everything
+      // this wave has issued is done (loads and stores count together, in order) the macroblock is published.
       if (linePend) {
         wv::wait_vm(0);
         const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
@@ -483,40 +560,19 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         linePend = false;
       }
       if (needUp) {
-        // the band above must have finished macroblock s+1 (neighbour C of row 0) before its lines are fetched. Its
-        // progress word is read one step ahead (flagV), so this normally costs nothing; otherwise poll.
+        // the band above must have finished macroblock s+1 before its lines are fetched. Its progress word is read
+        // one step ahead (flagV), so this normally costs nothing; otherwise poll.
         if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
         flagPend = false;
-        const unsigned need = (unsigned)min(s + 2, W);
-        unsigned spins = 0;
-        TRACE(2, (s << 16) | need);
-        while (upKnown < need) {
-          const unsigned v = wv::ld_sc1(upProg);  // (all lanes, one address: one request)
-          upKnown = (unsigned)wv::rfl((int)v);
-          if (upKnown < need) {
-            wv::sleep_short();
-            if (++spins > SPIN_LIMIT) {
-              // every spin is bounded: a band above that never gets there is reported (status bit 2 + where), not waited for
-              if (lane == 0) {
-                wv::atomic_or(A.status, 4u);
-                A.status[1] = task;
-                A.status[2] = ((unsigned)s << 16) | need;
-                A.status[3] = upKnown;
-              }
-              upKnown = (unsigned)W;
-            }
-          }
-        }
-        TRACE(3, (s << 16) | upKnown);
+        upKnown = poll_progress(upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
         wv::compiler_fence();
-        // lanes 0..8: macroblock s+1 (0..3 Y, 4..5 Cb, 6..7 Cr, 8 modes); lanes 16..24: macroblock 0 at step 0
+        // lanes 0..4: macroblock s+1 (0..1 Cb, 2..3 Cr, 4 modes); lanes 16..20: macroblock 0 at step 0
         const int li = lane & 15;
         const int mbx = lane < 16 ? s + 1 : 0;
-        const bool act = li < 9 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+        const bool act = li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
         if (act) {
-          if (li < 8) {
-            const unsigned off = li < 4 ? (unsigned)((16 * r0 - 1) * pitchY + 16 * mbx + 4 * li)
-                                        : (li < 6 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
+          if (li < 4) {
+            const unsigned off = (li < 2 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
             lineV = wv::ld_sc1((const unsigned*)(planeY + off));
           } else {
             lineV = wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mbx)));
@@ -528,30 +584,27 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         }
       }
       load_coefs_luma(s + 1, kN1);  // (into the registers the residual pass has just freed)
-      PH(4);  // hand-off traffic, coefficient prefetch
-      // Intra4x4 macroblocks: the chain reads its residuals from LDS, [blkIdx][y][x]
-      if (kind == 0) {
-        wv::lds_st128(ws + S_RES + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
-        wv::lds_st128(ws + S_RES + 512 * g + 32 * i + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
-      }
+      PH(3);  // hand-off traffic, coefficient prefetch
 
-      // ================= neighbour lines of the row above ========================================================
-      // (step 0 of a band below another: macroblock 0's lines have only just been requested)
-      if (needUp && s == 0) {
+      // ---- the step's record for BACK: residuals [blkIdx][y][x], table rows, kinds. The buffer is free once BACK has
+      // finished the step two back.
+      if (gstep >= 2) team_wait(ts + S_FLAGS + 8 + 4 * buf, gstep - 1);
+      wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
+      wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
+      if (i == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 4 * g, (unsigned)kind | ((unsigned)i16mode << 8));
+      if (lane == 0) {
+        wv::lds_st32(ts + S_INFO + 32 * buf + 16, task);
+        wv::lds_st32(ts + S_INFO + 32 * buf + 20, (unsigned)s);
+      }
+      // chroma lines + modes of the band above: this step's fetched macroblock goes into row 0's ring
+      if (needUp) {
         const int li = lane & 15;
-        if (li < 9 && lane >= 16 && lane < 32) wv::lds_st32(ws + S_RING + 4 * li, lineV);
-      }
-      wv::wave_sync();
-      // top border of the luma tile, first part: corner dword of x-1, 16 bytes of x
-      if (i < 5) {
-        const int e = i == 0 ? x - 1 : x;
-        const int so = i == 0 ? 12 : 4 * (i - 1);
-        const unsigned v = wv::lds_u32(ringMine + RING_ENT * (e & 3) + so);
-        wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
+        const int mbx = lane < 16 ? s + 1 : 0;
+        const bool act = li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+        if (act) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * li, lineV);
       }
       wv::wave_sync();
 
-      PH(5);  // residual store, top border
       // ================= Intra4x4 prediction modes (8.3.1.1, pred4x4.rs:363-427) ==================================
       // mode grid = raster block grid, one DPP row per macroblock. Relaxation: after sweep k every block with
       // bx + by <= k is final.
@@ -561,7 +614,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         const int mzb = zidx(rbx, rby);
         const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
         const bool prev = ((prevFlags >> mzb) & 1u) != 0;
-        const unsigned upM = mbB ? wv::lds_u32(ringMine + RING_ENT * (x & 3) + 32) : 0x02020202u;
+        const unsigned upM = mbB ? wv::lds_u32(ringC + RINGC_ENT * (x & 3) + 16) : 0x02020202u;
         const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
         const int Lb = wv::dpp<DPP_ROW_SHL(3)>(Mprev, Mprev);
         const bool unav = (rbx == 0 && !mbA) || (rby == 0 && !mbB);
@@ -589,84 +642,14 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
           Mcur = M;
           const int t = rbx + 2 * rby;
           const int hh = rby != stepByLo(t) ? 1 : 0;
-          wv::lds_st8(ws + S_MSEQ + 24 * g + 12 * hh + t, (unsigned)Mp);
+          wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + 12 * hh + t, (unsigned)Mp);
         }
       }
 
-      PH(6);  // modes
-      // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
-      if (wv::any(valid && kind >= 2)) {
-        const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
-        const unsigned lw = wv::lds_u32(ws + S_LEFTY + 16 * g + 4 * zby);
-        unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
-        {
-          // DC: one reduction over the row group of the available sums
-          int sm = ((zby == 0 && mbB) ? (int)wv::sad4(tw) : 0) + ((zbx == 0 && mbA) ? (int)wv::sad4(lw) : 0);
-          sm += xor8(sm);
-          sm += xor4(sm, (i & 4) != 0);
-          sm += xor2(sm);
-          sm += xor1(sm);
-          const int v = (mbA && mbB) ? (sm + 16) >> 5 : (mbA || mbB) ? (sm + 8) >> 4 : 128;
-          if (i16mode == 2) src = (unsigned)v * 0x01010101u;
-        }
-        if (i16mode == 0) {
-          src = mbB ? tw : 0u;
-          selA = 0x0c010c00u;
-          selB = 0x0c030c02u;
-          inc = 0;
-        } else if (i16mode == 1) {
-          if (!mbA) src = 0;
-        } else if (i16mode == 3) {
-          src = 0;
-        }
-        unsigned p01[4], p23[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          p01[k] = wv::perm(src, src, selA + inc * k);
-          p23[k] = wv::perm(src, src, selB + inc * k);
-        }
-        if (wv::any(valid && kind == 2 && i16mode == 3)) {
-          // plane (:366-424): lanes 0..7 of the row group: horizontal terms, 8..15: vertical terms
-          const int k = i & 7;
-          const int tr0 = tile + 8 + 16 * slot, lf = ws + S_LEFTY + 16 * g;
-          const int corner = (int)wv::lds_u8(tr0 - 1);
-          const int ha = (int)wv::lds_u8(tr0 + 8 + k), hb = k == 7 ? corner : (int)wv::lds_u8(tr0 + 6 - k);
-          const int va = (int)wv::lds_u8(lf + 8 + k), vb = k == 7 ? corner : (int)wv::lds_u8(lf + 6 - k);
-          int term = (k + 1) * (i < 8 ? ha - hb : va - vb);
-          term += xor1(term);
-          term += xor2(term);
-          term += xor4(term, (i & 4) != 0);  // lanes 0..7: H, lanes 8..15: V
-          const int hs = wv::bperm(term, lane & 48), vs = wv::bperm(term, (lane & 48) + 8);
-          if (kind == 2 && i16mode == 3 && mbA && mbB) {
-            const int a = 16 * ((int)wv::lds_u8(lf + 15) + (int)wv::lds_u8(tr0 + 15));
-            const int bq = (5 * hs + 32) >> 6, c = (5 * vs + 32) >> 6;
-            const int base = a + bq * (4 * zbx - 7) + c * (4 * zby - 7) + 16;
-            const unsigned b01 = ((unsigned)base & 0xffffu) | ((unsigned)(base + bq) << 16);
-            const unsigned step2 = ((unsigned)(2 * bq) & 0xffffu) | ((unsigned)(2 * bq) << 16);
-            const unsigned cc = ((unsigned)c & 0xffffu) | ((unsigned)c << 16);
-            unsigned q01 = b01, q23 = wv::pk_add(b01, step2);
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-              const unsigned u01 = wv::sat_pk_u8(wv::pk_ashr5(q01)), u23 = wv::sat_pk_u8(wv::pk_ashr5(q23));
-              p01[kk] = wv::perm(0u, u01, 0x0c010c00u);
-              p23[kk] = wv::perm(0u, u23, 0x0c010c00u);
-              q01 = wv::pk_add(q01, cc);
-              q23 = wv::pk_add(q23, cc);
-            }
-          }
-        }
-        if (kind >= 2) {
-          if (kind == 3) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
-          }
-          const int dst = tile + TILE_STRIDE * (4 * zby + 1) + 8 + 16 * slot + 4 * zbx;
-#pragma unroll
-          for (int k = 0; k < 4; k++) wv::lds_st32(dst + TILE_STRIDE * k, recon_row(p01[k], p23[k], rA[2 * k], rA[2 * k + 1]));
-        }
-      }
+      wv::wave_sync();
+      if (lane == 0) wv::lds_st32(ts + S_FLAGS + 4 * buf, gstep + 1);  // the record is complete
+      PH(4);  // record for BACK, modes
 
-      PH(7);  // Intra16x16
       // ================= chroma residuals ==========================================================================
       unsigned rB[8];
       {
@@ -692,12 +675,12 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
       dN1 = load_desc(s + 1);
       kN2 = load_kind(s + 2);
 
-      PH(8);  // chroma residuals, prefetch
+      PH(5);  // chroma residuals, prefetch
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (row gc, plane, block) ===================
       {
-        const int ringC = ws + S_RING + RING_ROW * gc + 16 + 8 * cpl;
-        const int leftC = ws + S_LEFTC + 16 * gc + 8 * cpl;
-        const unsigned tw = wv::lds_u32(ringC + RING_ENT * (xC & 3) + 4 * ccx);
+        const int ringP = ts + S_RINGC + RINGC_ROW * gc + 8 * cpl;
+        const int leftC = ts + S_LEFTC + 16 * gc + 8 * cpl;
+        const unsigned tw = wv::lds_u32(ringP + RINGC_ENT * (xC & 3) + 4 * ccx);
         const unsigned lw = wv::lds_u32(leftC + 4 * ccy);
         unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
         if (cmode == 0) {
@@ -732,8 +715,8 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
         if (wv::any(chromaLane && validC && kindC != 3 && cmode == 3)) {
           // plane (:319-363): H = sum (k+1)(T[4+k] - T[2-k]), V likewise on the left column; T[-1] = L[-1] = corner
           const int k = cblk;
-          const int rT = ringC + RING_ENT * (xC & 3);
-          const int corner = (int)wv::lds_u8(ringC + RING_ENT * ((xC - 1) & 3) + 7);
+          const int rT = ringP + RINGC_ENT * (xC & 3);
+          const int corner = (int)wv::lds_u8(ringP + RINGC_ENT * ((xC - 1) & 3) + 7);
           const int ha = (int)wv::lds_u8(rT + 4 + k), hb = k == 3 ? corner : (int)wv::lds_u8(rT + 2 - k);
           const int va = (int)wv::lds_u8(leftC + 4 + k), vb = k == 3 ? corner : (int)wv::lds_u8(leftC + 2 - k);
           int hs = (k + 1) * (ha - hb), vs = (k + 1) * (va - vb);
@@ -765,7 +748,7 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
           for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
         }
         if (chromaLane) {
-          const int st = ws + S_STC + 256 * gc + 128 * cpl + 16 * (4 * ccy) + 8 * slot + 4 * ccx;
+          const int st = ts + S_STC + 256 * gc + 128 * cpl + 16 * (4 * ccy) + 8 * slot + 4 * ccx;
 #pragma unroll
           for (int k = 0; k < 4; k++) wv::lds_st32(st + 16 * k, recon_row(p01[k], p23[k], rB[2 * k], rB[2 * k + 1]));
         }
@@ -773,28 +756,286 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
 
       wv::wave_sync();
 
-      PH(9);  // chroma prediction
+      wv::wave_sync();
+      PH(6);  // chroma prediction
+
+      // ================= chroma write-out =========================================================================
+      // The prefetched record and coefficients are "used" here, in front of this step's stores: the compiler then
+      // waits for those loads now (they were issued thousands of cycles ago) instead of at the top of the next step,
+      // where its vmcnt(0) would also wait for the stores below -- and a write-through store takes thousands of cycles
+      // to be acknowledged when the chip is busy. (Measured alternative, not kept: a constant number of stores per step,
+      // padded with stores to a dump area, so that the compiler could count them: its waits stayed vmcnt(0) across the
+      // loop back-edge and the batch took longer.)
+      dN1.x = (unsigned)wv::opaque((int)dN1.x); dN1.y = (unsigned)wv::opaque((int)dN1.y);
+      dN1.z = (unsigned)wv::opaque((int)dN1.z); dN1.w = (unsigned)wv::opaque((int)dN1.w);
+      kN2 = (unsigned)wv::opaque((int)kN2);
+      cA0.x = (unsigned)wv::opaque((int)cA0.x); cA1.x = (unsigned)wv::opaque((int)cA1.x); dcA = wv::opaque(dcA);
+      cB0.x = (unsigned)wv::opaque((int)cB0.x); cB1.x = (unsigned)wv::opaque((int)cB1.x); dcB = wv::opaque(dcB);
+      // bottom chroma lines and bottom-row modes for the row below (ring) or the band below (write-through)
+      const unsigned m4 = [&]() {
+        unsigned v = (unsigned)Mcur << (8 * (i & 3));
+        v |= (unsigned)xor1((int)v);
+        v |= (unsigned)xor2((int)v);
+        return v;  // lanes 12..15 of the row group: the four bottom-row modes
+      }();
+      {
+        // lanes of row g: 0..1 Cb dwords, 2..3 Cr (bottom line), 12: modes
+        const int stc = ts + S_STC + 256 * g;
+        unsigned v = 0;
+        if (i < 4) v = wv::lds_u32(stc + 128 * (i >> 1) + 16 * 7 + 8 * slot + 4 * (i & 1));
+        else if (i == 12) v = m4;
+        const bool lineLane = i < 4 || i == 12;
+        const int fo = i < 4 ? 4 * i : 16;
+        if (valid && lineLane && g < 3 && g < gl) wv::lds_st32(ts + S_RINGC + RINGC_ROW * (g + 1) + RINGC_ENT * (x & 3) + fo, v);
+        if (hasBelow && wv::any(valid && g == gl)) {  // the band's last row: written through for the band below
+          if (valid && g == gl && lineLane) {
+            if (i < 4) {
+              const unsigned off = (i < 2 ? offCb : offCr) + (unsigned)((8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
+              wv::st_sc1((unsigned*)(planeY + off), v);
+            } else {
+              wv::st_sc1((unsigned*)(modesF + 4u * (unsigned)(r * W + x)), v);
+            }
+          }
+          linePend = true;
+        }
+      }
+      // left neighbour copy: chroma column 7
+      {
+        const int pl = i >> 3, yy = i & 7;
+        const unsigned c = wv::lds_u8(ts + S_STC + 256 * g + 128 * pl + 16 * yy + 8 * slot + 7);
+        wv::lds_st8(ts + S_LEFTC + 16 * g + 8 * pl + yy, c);
+      }
+      Mprev = valid ? Mcur : 2;
+      wv::wave_sync();
+      // flush the staged rows: every second macroblock, or at the end of a row: 16 contiguous bytes per pixel row.
+      // The bottom lines of a band that has a band below were already written through.
+      if (wv::any(valid && (slot == 1 || x == W - 1))) {
+        const int fg = lane >> 4, pl = (lane >> 3) & 1, fy = lane & 7;
+        const int fx = s - 2 * fg, xp = fx & ~1;
+        const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && !(hasBelow && fg == gl && fy == 7);
+        const u32x4 v = wv::lds_u128(ts + S_STC + 256 * fg + 128 * pl + 16 * fy);
+        uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp));
+        if (ok) {
+          if (xp + 1 <= fx) wv::st_g128(dst, v);
+          else wv::st_g64(dst, u32x2{v.x, v.y});
+        }
+      }
+      wv::wave_sync();
+      PH(7);  // chroma lines, copies, flush
+    }
+    // the band's chroma is complete once its last stores have been written through
+    if (hasBelow) {
+      wv::wait_vm(0);
+      if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
+    }
+    TRACE(6, task + 1u);
+  }
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  TRACE(7, 0xD0E);
+  if (lane0 == 0 && A.profile)
+    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
+#endif
+}
+
+// ==================================================================================================================
+// BACK wave: luma prediction and write-out, driven by the records FRONT leaves in LDS
+// ==================================================================================================================
+template <bool HAS_I8>
+WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int ts) {
+  const int lane0 = wv::lane_id();
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  unsigned long long phAcc[BAND_NPH];
+  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
+  unsigned long long phT = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+  const int W = P.W, H = P.H, nF = P.n_frames;
+  const int nBands = (H + 3) >> 2;
+  const int pitchY = W * 16;
+  const size_t frameBytes = (size_t)W * H * 384;
+  // per-task state (set at step 0 of each task)
+  BandGeo G = band_geo(0u, nF, W, H);
+  uint8_t* planeY = A.yuv;
+  unsigned* myProg = A.progY;
+  unsigned upKnown = 0, flagV = 0;
+  bool flagPend = false, linePend = false;
+
+  for (unsigned gstep = 0;; gstep++) {
+    const int buf = (int)(gstep & 1u);
+    team_wait(ts + S_FLAGS + 4 * buf, gstep + 1);
+    const unsigned task = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 16));
+    if (task == TASK_END) break;
+    const int s = wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 20));
+    if (s == 0) {
+      G = band_geo(task, nF, W, H);
+      planeY = A.yuv + (size_t)G.f * frameBytes;
+      myProg = A.progY + (size_t)G.f * nBands + G.b;
+      upKnown = 0;
+      flagPend = false;
+      linePend = false;
+    }
+    const int r0 = G.r0, nR = G.nR, gl = G.gl;
+    const bool hasAbove = G.hasAbove, hasBelow = G.hasBelow;
+    const unsigned* const upProg = myProg - 1;
+    const int resBuf = ts + S_RES + 2048 * buf;
+
+    const int lane = wv::opaque(lane0);
+    const int g = lane >> 4, i = lane & 15;
+    const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
+    const int ch = (i >> 3) & 1, cp = i & 7;                                          // Intra4x4 chain: block half, pixel pair
+    const int tile = ts + S_TILE + TILE_BYTES * g;
+    const int ringMine = ts + S_RINGY + 64 * g;         // luma lines of the row above row g
+    const int r = r0 + g;
+    const bool rowOk = g < nR;
+    const bool mbB = r > 0;
+    const int x = s - 2 * g;
+    const bool valid = rowOk && x >= 0 && x < W;
+    const bool mbA = x > 0;
+    const int slot = s & 1;  // (x & 1 for every row)
+    const bool needUp = hasAbove && s < W;
+    const unsigned info = wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g);
+    const int kind = (int)(info & 0xffu), i16mode = (int)((info >> 8) & 0xffu);
+    unsigned lineV = 0;
+    PH(8);  // wait for the record
+
+    // ---- band above: its last row must have finished macroblock s+1 (neighbour C of row 0); fetch that macroblock's
+    // bottom luma line; the progress word for the next step is fetched too
+    if (needUp) {
+      if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
+      flagPend = false;
+      upKnown = poll_progress(upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
+      wv::compiler_fence();
+      // lanes 0..3: macroblock s+1; lanes 16..19: macroblock 0 at step 0
+      const int li = lane & 15;
+      const int mbx = lane < 16 ? s + 1 : 0;
+      const bool act = li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+      if (act) lineV = wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mbx + 4 * li)));
+      if (upKnown < (unsigned)W) {
+        flagV = wv::ld_sc1(upProg);
+        flagPend = true;
+      }
+      // (step 0 of a band below another: macroblock 0's line has only just been requested)
+      if (s == 0 && li < 4 && lane >= 16 && lane < 32) wv::lds_st32(ts + S_RINGY + 4 * li, lineV);
+    }
+    wv::wave_sync();
+    // top border of the luma tile, first part: corner dword of x-1, 16 bytes of x
+    if (i < 5) {
+      const int e = i == 0 ? x - 1 : x;
+      const int so = i == 0 ? 12 : 4 * (i - 1);
+      const unsigned v = wv::lds_u32(ringMine + 16 * (e & 3) + so);
+      wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
+    }
+    wv::wave_sync();
+    PH(9);  // hand-off traffic, top border
+
+      // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
+      if (wv::any(valid && kind >= 2)) {
+        const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
+        const unsigned lw = wv::lds_u32(ts + S_LEFTY + 16 * g + 4 * zby);
+        unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
+        {
+          // DC: one reduction over the row group of the available sums
+          int sm = ((zby == 0 && mbB) ? (int)wv::sad4(tw) : 0) + ((zbx == 0 && mbA) ? (int)wv::sad4(lw) : 0);
+          sm += xor8(sm);
+          sm += xor4(sm, (i & 4) != 0);
+          sm += xor2(sm);
+          sm += xor1(sm);
+          const int v = (mbA && mbB) ? (sm + 16) >> 5 : (mbA || mbB) ? (sm + 8) >> 4 : 128;
+          if (i16mode == 2) src = (unsigned)v * 0x01010101u;
+        }
+        if (i16mode == 0) {
+          src = mbB ? tw : 0u;
+          selA = 0x0c010c00u;
+          selB = 0x0c030c02u;
+          inc = 0;
+        } else if (i16mode == 1) {
+          if (!mbA) src = 0;
+        } else if (i16mode == 3) {
+          src = 0;
+        }
+        unsigned p01[4], p23[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          p01[k] = wv::perm(src, src, selA + inc * k);
+          p23[k] = wv::perm(src, src, selB + inc * k);
+        }
+        if (wv::any(valid && kind == 2 && i16mode == 3)) {
+          // plane (:366-424): lanes 0..7 of the row group: horizontal terms, 8..15: vertical terms
+          const int k = i & 7;
+          const int tr0 = tile + 8 + 16 * slot, lf = ts + S_LEFTY + 16 * g;
+          const int corner = (int)wv::lds_u8(tr0 - 1);
+          const int ha = (int)wv::lds_u8(tr0 + 8 + k), hb = k == 7 ? corner : (int)wv::lds_u8(tr0 + 6 - k);
+          const int va = (int)wv::lds_u8(lf + 8 + k), vb = k == 7 ? corner : (int)wv::lds_u8(lf + 6 - k);
+          int term = (k + 1) * (i < 8 ? ha - hb : va - vb);
+          term += xor1(term);
+          term += xor2(term);
+          term += xor4(term, (i & 4) != 0);  // lanes 0..7: H, lanes 8..15: V
+          const int hs = wv::bperm(term, lane & 48), vs = wv::bperm(term, (lane & 48) + 8);
+          if (kind == 2 && i16mode == 3 && mbA && mbB) {
+            const int a = 16 * ((int)wv::lds_u8(lf + 15) + (int)wv::lds_u8(tr0 + 15));
+            const int bq = (5 * hs + 32) >> 6, c = (5 * vs + 32) >> 6;
+            const int base = a + bq * (4 * zbx - 7) + c * (4 * zby - 7) + 16;
+            const unsigned b01 = ((unsigned)base & 0xffffu) | ((unsigned)(base + bq) << 16);
+            const unsigned step2 = ((unsigned)(2 * bq) & 0xffffu) | ((unsigned)(2 * bq) << 16);
+            const unsigned cc = ((unsigned)c & 0xffffu) | ((unsigned)c << 16);
+            unsigned q01 = b01, q23 = wv::pk_add(b01, step2);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              const unsigned u01 = wv::sat_pk_u8(wv::pk_ashr5(q01)), u23 = wv::sat_pk_u8(wv::pk_ashr5(q23));
+              p01[kk] = wv::perm(0u, u01, 0x0c010c00u);
+              p23[kk] = wv::perm(0u, u23, 0x0c010c00u);
+              q01 = wv::pk_add(q01, cc);
+              q23 = wv::pk_add(q23, cc);
+            }
+          }
+        }
+        if (kind >= 2) {
+          if (kind == 3) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
+          }
+          const u32x4 ra = wv::lds_u128(resBuf + 512 * g + 32 * i), rb = wv::lds_u128(resBuf + 512 * g + 32 * i + 16);
+          const unsigned rA[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+          const int dst = tile + TILE_STRIDE * (4 * zby + 1) + 8 + 16 * slot + 4 * zbx;
+#pragma unroll
+          for (int k = 0; k < 4; k++) wv::lds_st32(dst + TILE_STRIDE * k, recon_row(p01[k], p23[k], rA[2 * k], rA[2 * k + 1]));
+        }
+      }
+
+      wv::wave_sync();
+      PH(10);  // Intra16x16
+
       // ================= top-right neighbour: the fetched macroblock s+1 goes into row 0's ring, then 8 bytes of x+1
       if (needUp) {
         const int li = lane & 15;
-        if (li < 9 && lane < 16 && s + 1 < W) wv::lds_st32(ws + S_RING + RING_ENT * ((s + 1) & 3) + 4 * li, lineV);
+        if (li < 4 && lane < 16 && s + 1 < W) wv::lds_st32(ts + S_RINGY + 16 * ((s + 1) & 3) + 4 * li, lineV);
         wv::wave_sync();
       }
       if (i == 5 || i == 6) {
-        const unsigned v = wv::lds_u32(ringMine + RING_ENT * ((x + 1) & 3) + 4 * (i - 5));
+        const unsigned v = wv::lds_u32(ringMine + 16 * ((x + 1) & 3) + 4 * (i - 5));
         wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
       }
       wv::wave_sync();
+      // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom line (and the
+      // staged row segments); this step's only load so far has just been consumed. Once vmcnt says that everything this
+      // wave has issued is done the macroblock is published.
+      if (linePend) {
+        wv::wait_vm(0);
+        const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
+        if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
+        linePend = false;
+      }
+      PH(11);  // top-right copy, publish
+      const bool anyI4 = wv::any(valid && kind == 0);
 
-      PH(10);  // top-right copy
       // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================
       // lane = (row g, block half ch, pixel pair cp): pixels (2*(cp&1) + {0,1}, cp>>1) of the step's block
       if (anyI4) {
         const bool mine = valid && kind == 0;
         const int px = 2 * (cp & 1), py = cp >> 1;
-        const int seqA = ws + S_MSEQ + 24 * g + 12 * ch;
+        const int seqA = ts + S_MSEQ + 96 * buf + 24 * g + 12 * ch;
         const int tOrg = tile + 8 + 16 * slot;   // row y = -1, x = 0 of the macroblock
-        const int resB = ws + S_RES + 512 * g + 4 * cp;
+        const int resB = resBuf + 512 * g + 4 * cp;
         const int entB = ldsBase + T_T4E + 8 * cp;
         // the table rows of all ten steps (they do not depend on pixels), then entry and residual one step ahead
         const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
@@ -840,64 +1081,31 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
 #undef I4_STEP
       }
 
-      TRACE(4, s + 1);
-      PH(11);  // Intra4x4 chain
-      // ================= write-out ================================================================================
-      // The prefetched record and coefficients are "used" here, in front of this step's stores: the compiler then
-      // waits for those loads now (they were issued thousands of cycles ago) instead of at the top of the next step,
-      // where its vmcnt(0) would also wait for the stores below -- and a write-through store takes thousands of cycles
-      // to be acknowledged when the chip is busy. (Measured alternative, not kept: a constant number of stores per step,
-      // padded with stores to a dump area, so that the compiler could count them: its waits stayed vmcnt(0) across the
-      // loop back-edge and the batch took 2.67 ms instead of 2.45.)
-      dN1.x = (unsigned)wv::opaque((int)dN1.x); dN1.y = (unsigned)wv::opaque((int)dN1.y);
-      dN1.z = (unsigned)wv::opaque((int)dN1.z); dN1.w = (unsigned)wv::opaque((int)dN1.w);
-      kN2 = (unsigned)wv::opaque((int)kN2);
-      cA0.x = (unsigned)wv::opaque((int)cA0.x); cA1.x = (unsigned)wv::opaque((int)cA1.x); dcA = wv::opaque(dcA);
-      cB0.x = (unsigned)wv::opaque((int)cB0.x); cB1.x = (unsigned)wv::opaque((int)cB1.x); dcB = wv::opaque(dcB);
-      // bottom lines and modes for the row below (ring) or the band below (write-through)
-      const unsigned m4 = [&]() {
-        unsigned v = (unsigned)Mcur << (8 * (i & 3));
-        v |= (unsigned)xor1((int)v);
-        v |= (unsigned)xor2((int)v);
-        return v;  // lanes 12..15 of the row group: the four bottom-row modes
-      }();
+      // the record has been consumed
+      wv::wave_sync();
+      if (lane == 0) wv::lds_st32(ts + S_FLAGS + 8 + 4 * buf, gstep + 1);
+      PH(12);  // Intra4x4 chain
+
+      // ================= luma write-out ============================================================================
       {
-        // lanes of row g: 0..3 Y dwords, 4..5 Cb, 6..7 Cr (bottom line), 12: modes
-        const int stc = ws + S_STC + 256 * g;
+        // bottom line for the row below (ring) or the band below (write-through): lanes 0..3 of row g
         unsigned v = 0;
         if (i < 4) v = wv::lds_u32(tile + TILE_STRIDE * 16 + 8 + 16 * slot + 4 * i);
-        else if (i < 8) v = wv::lds_u32(stc + 128 * ((i >> 1) & 1) + 16 * 7 + 8 * slot + 4 * (i & 1));
-        else if (i == 12) v = m4;
-        const bool lineLane = i < 8 || i == 12;
-        const int fo = i < 8 ? 4 * i : 32;
-        if (valid && lineLane && g < 3 && g < gl) wv::lds_st32(ringBelow + RING_ENT * (x & 3) + fo, v);
-        if (hasBelow && wv::any(valid && g == gl)) {  // the band's last row: written through for the band below
-          if (valid && g == gl && lineLane) {
-            if (i < 8) {
-              const unsigned off = i < 4 ? (unsigned)((16 * r + 15) * pitchY + 16 * x + 4 * i)
-                                         : (i < 6 ? offCb : offCr) + (unsigned)((8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
-              wv::st_sc1((unsigned*)(planeY + off), v);
-            } else {
-              wv::st_sc1((unsigned*)(modesF + 4u * (unsigned)(r * W + x)), v);
-            }
-          }
+        if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ts + S_RINGY + 64 * (g + 1) + 16 * (x & 3) + 4 * i, v);
+        if (hasBelow && wv::any(valid && g == gl)) {
+          if (valid && g == gl && i < 4) wv::st_sc1((unsigned*)(planeY + (unsigned)((16 * r + 15) * pitchY + 16 * x + 4 * i)), v);
           linePend = true;
         }
       }
-      // left neighbour copies: luma column 15 (also the tile's x = -1 border when the next macroblock is slot 0)
+      // left neighbour copy: luma column 15 (also the tile's x = -1 border when the next macroblock is slot 0)
       {
         const unsigned v = wv::lds_u8(tile + TILE_STRIDE * (i + 1) + 8 + 16 * slot + 15);
-        wv::lds_st8(ws + S_LEFTY + 16 * g + i, v);
+        wv::lds_st8(ts + S_LEFTY + 16 * g + i, v);
         if (slot == 1) wv::lds_st8(tile + TILE_STRIDE * (i + 1) + 7, v);
-        const int pl = i >> 3, yy = i & 7;
-        const unsigned c = wv::lds_u8(ws + S_STC + 256 * g + 128 * pl + 16 * yy + 8 * slot + 7);
-        wv::lds_st8(ws + S_LEFTC + 16 * g + 8 * pl + yy, c);
       }
-      Mprev = valid ? Mcur : 2;
       wv::wave_sync();
-      PH(12);  // lines, left copies
-      // flush the staged rows: every second macroblock, or at the end of a row. 32 (luma) / 16 (chroma) contiguous
-      // bytes per pixel row. The bottom lines of a band that has a band below were already written through.
+      // flush the staged rows: every second macroblock, or at the end of a row: 32 contiguous bytes per pixel row.
+      // The bottom line of a band that has a band below was already written through.
       if (wv::any(valid && (slot == 1 || x == W - 1))) {
 #pragma unroll
         for (int it = 0; it < 2; it++) {
@@ -906,36 +1114,20 @@ WV void band_wave(const KParams& P, const Args& A, const int ldsBase, const int 
           const int fx = s - 2 * fg, xp = fx & ~1;
           const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && xp + half <= fx &&
                           !(hasBelow && fg == gl && fy == 15);
-          const int src = ws + S_TILE + TILE_BYTES * fg + TILE_STRIDE * (fy + 1) + 8 + 16 * half;
+          const int src = ts + S_TILE + TILE_BYTES * fg + TILE_STRIDE * (fy + 1) + 8 + 16 * half;
           const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
           if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + half)), u32x4{lo.x, lo.y, hi.x, hi.y});
         }
-        {
-          const int fg = lane >> 4, pl = (lane >> 3) & 1, fy = lane & 7;
-          const int fx = s - 2 * fg, xp = fx & ~1;
-          const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && !(hasBelow && fg == gl && fy == 7);
-          const u32x4 v = wv::lds_u128(ws + S_STC + 256 * fg + 128 * pl + 16 * fy);
-          uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp));
-          if (ok) {
-            if (xp + 1 <= fx) wv::st_g128(dst, v);
-            else wv::st_g64(dst, u32x2{v.x, v.y});
-          }
-        }
       }
       wv::wave_sync();
-      PH(13);  // flush
-      TRACE(5, s + 1);
-    }
-    // the band is complete once its last stores have been written through
-    if (hasBelow) {
-      wv::wait_vm(0);
-      if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
-    }
-    TRACE(6, task + 1u);
-    PH(14);  // band tail
+      PH(13);  // line, copies, flush
+      // the band's luma is complete once its last stores have been written through
+      if (s == G.nSteps - 1 && hasBelow) {
+        wv::wait_vm(0);
+        if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
+      }
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  TRACE(7, 0xD0E);
   if (lane0 == 0 && A.profile)
     for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
 #endif

@@ -73,7 +73,7 @@ int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
 }
 
 size_t workspace_bytes(const KParams& P) {
-  size_t b = dryv::recon_workspace_bytes(P.W, P.H, P.n_frames);
+  size_t b = std::max(dryv::recon_workspace_bytes(P.W, P.H, P.n_frames), dryv::band_workspace_bytes(P));
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
   b = dryv::band_profile_offset(P) + (size_t)65536 * 16 * 8 + (size_t)65536 * 32;
 #endif
@@ -83,11 +83,11 @@ size_t workspace_bytes(const KParams& P) {
 int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, bool wide) {
   hipError_t e;
   const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
-  const int wpb = dryv::band_waves_per_block();
+  const int wpb = dryv::band_teams_per_block();
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
   if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
   if (grid < 1) grid = 1;
-  e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
+  e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
   e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_profile_offset(P), 0, (size_t)65536 * 16 * 8 + (size_t)65536 * 32, ctx->stream);
@@ -344,7 +344,7 @@ int dryv_recon_debug_band_trace(dryv_recon_ctx* ctx, int n_waves, unsigned* out,
   if (!s2 && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return DRYV_E_DEVICE;
   hipError_t e = hipMemcpyAsync(out, (unsigned char*)ctx->d_work + dryv::band_profile_offset(ctx->last_P) + (size_t)65536 * 16 * 8,
                                 (size_t)n_waves * 32, hipMemcpyDeviceToHost, s2);
-  if (e == hipSuccess && n_prog > 0) e = hipMemcpyAsync(prog_out, (unsigned char*)ctx->d_work + 256, (size_t)n_prog * 4, hipMemcpyDeviceToHost, s2);
+  if (e == hipSuccess && n_prog > 0) e = hipMemcpyAsync(prog_out, (unsigned char*)ctx->d_work + 256, (size_t)n_prog * 4, hipMemcpyDeviceToHost, s2);  /* luma words, then chroma words */
   if (e == hipSuccess) e = hipStreamSynchronize(s2);
   return e == hipSuccess ? DRYV_OK : DRYV_E_DEVICE;
 }

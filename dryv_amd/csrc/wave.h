@@ -110,6 +110,7 @@ WV void wait_vm(int n) {
 #endif
 WV void sleep_short() { __builtin_amdgcn_s_sleep(DRYV_BAND_SLEEP); }
 WV void sleep_long() { __builtin_amdgcn_s_sleep(32); }
+WV void sleep_team() { __builtin_amdgcn_s_sleep(1); }  // between two polls of the partner wave's LDS flag
 WV void compiler_fence() { asm volatile("" ::: "memory"); }
 // the value, behind a barrier the optimiser cannot see through: what is derived from it is recomputed, not kept live
 WV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -132,7 +133,8 @@ struct EmuState {
   int xbuf[64];
   unsigned long long xbuf64[64];
   const char* tag[64];
-  uint8_t lds[163840];
+  uint8_t* lds;      // the workgroup's LDS (shared by the waves of a team)
+  int lds_bytes;
 };
 extern EmuState* g_emu_cur;  // the wave that is running (several waves are interleaved: see band_emu.cpp)
 #define g_emu (*g_emu_cur)
@@ -189,7 +191,7 @@ WV unsigned long long ballot(bool p) {
 WV bool any(bool p) { return ballot(p) != 0ull; }
 
 WV void emu_lds_check(int a, int n) {
-  if (a < 0 || a + n > (int)sizeof(g_emu.lds) || (a % (n > 8 ? 8 : n)) != 0) {
+  if (a < 0 || a + n > g_emu.lds_bytes || (a % (n > 8 ? 8 : n)) != 0) {
     fprintf(stderr, "emu: bad LDS access addr %d size %d (lane %d)\n", a, n, lane_id());
     abort();
   }
@@ -253,6 +255,7 @@ WV void wait_vm(int) {}
 // a poll that failed: the wave yields to the other emulated waves (all 64 lanes get here together)
 WV void sleep_short() { emu_barrier("@sleep"); }
 WV void sleep_long() { emu_barrier("@sleep"); }
+WV void sleep_team() { emu_barrier("@sleep"); }
 WV void compiler_fence() {}
 WV int opaque(int v) { return v; }
 

@@ -51,7 +51,6 @@ static void trampoline() {
 static void init_wave(Wave* w) {
   const size_t SS = 384 * 1024;
   w->stacks.resize(64 * SS);
-  memset(w->st.lds, 0xA5, sizeof(w->st.lds));
   for (int l = 0; l < 64; l++) {
     getcontext(&w->fiber[l]);
     w->fiber[l].uc_stack.ss_sp = w->stacks.data() + l * SS;
@@ -95,25 +94,33 @@ static dryv::band::Args g_A;
 static bool g_wide;
 static int wave_index() { return wv::g_wave->index; }
 static void body() {
-  if (g_wide) {
-    if (g_P.transform8x8) dryv::band::band_wave<true, true>(g_P, g_A, 0, dryv::band::T_END_I8);
-    else dryv::band::band_wave<false, true>(g_P, g_A, 0, dryv::band::T_END);
+  using namespace dryv::band;
+  const bool back = (wave_index() & 1) != 0;  // waves 2t / 2t+1 = FRONT / BACK of team t (each team has its own LDS here)
+  const bool i8 = g_P.transform8x8 != 0;
+  const int ts = i8 ? T_END_I8 : T_END;
+  if (back) {
+    if (i8) band_back<true>(g_P, g_A, 0, ts);
+    else band_back<false>(g_P, g_A, 0, ts);
+  } else if (g_wide) {
+    if (i8) band_front<true, true>(g_P, g_A, 0, ts);
+    else band_front<false, true>(g_P, g_A, 0, ts);
   } else {
-    if (g_P.transform8x8) dryv::band::band_wave<true, false>(g_P, g_A, 0, dryv::band::T_END_I8);
-    else dryv::band::band_wave<false, false>(g_P, g_A, 0, dryv::band::T_END);
+    if (i8) band_front<true, false>(g_P, g_A, 0, ts);
+    else band_front<false, false>(g_P, g_A, 0, ts);
   }
 }
 
-// n_waves = 1: one wave takes every band in queue order (dependencies always already satisfied).
-// n_waves > 1: that many waves claim bands concurrently, scheduled round-robin from wave `first`, `order` = +1 / -1.
+// n_teams teams (a FRONT and a BACK wave each, sharing one LDS array) claim bands concurrently; the 2 * n_teams waves are
+// scheduled round-robin from wave `first`, `order` = +1 / -1, each until it polls in vain or finishes.
 extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_frames, const dryv_mb_desc* mbs,
-                                    const int16_t* coeffs, uint8_t* yuv, unsigned* status_out, int n_waves, int first,
+                                    const int16_t* coeffs, uint8_t* yuv, unsigned* status_out, int n_teams, int first,
                                     int order) {
   int st = dryv::params::build_params(fp, n_frames, &g_P);
   if (st != DRYV_OK) return st;
-  if (n_waves < 1) n_waves = 1;
+  if (n_teams < 1) n_teams = 1;
+  const int n_waves = 2 * n_teams;
   const int nBands = (g_P.H + 3) / 4;
-  std::vector<unsigned> prog((size_t)n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H, 0xEEEEEEEEu);
+  std::vector<unsigned> prog((size_t)2 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H, 0xEEEEEEEEu);
   // like the host API: the fast build first; if it flags a block beyond int32 (status bit 1), the batch again with the wide build
   unsigned status[4] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; pass++) {
@@ -121,15 +128,22 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
     memset(status, 0, sizeof status);
     std::fill(prog.begin(), prog.end(), 0u);
     g_wide = pass == 1;
-    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), modes.data(), &counter, nullptr, 0};
+    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, modes.data(), &counter, nullptr, 0};
     wv::g_body = body;
     std::vector<std::unique_ptr<wv::Wave>> waves;
+    const int ldsBytes = (g_P.transform8x8 ? dryv::band::T_END_I8 : dryv::band::T_END) + dryv::band::S_BYTES;
+    std::vector<std::vector<uint8_t>> teamLds(n_teams, std::vector<uint8_t>(ldsBytes, 0xA5));
     for (int w = 0; w < n_waves; w++) {
       waves.emplace_back(new wv::Wave());
       waves.back()->index = w;
+      waves.back()->st.lds = teamLds[w >> 1].data();
+      waves.back()->st.lds_bytes = ldsBytes;
       wv::init_wave(waves.back().get());
       wv::g_emu_cur = &waves.back()->st;
-      dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
+      if ((w & 1) == 0) {
+        dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
+        memset(teamLds[w >> 1].data() + ldsBytes - dryv::band::S_BYTES + dryv::band::S_FLAGS, 0, 16);  // the team's flags
+      }
     }
     int live = n_waves;
     unsigned long long idle_rounds = 0;

@@ -24,7 +24,7 @@ def build(force=False):
     return SO
 
 
-def reconstruct(fp, n_frames, mbs, coeffs, n_waves=1, first=0, order=1):
+def reconstruct(fp, n_frames, mbs, coeffs, n_teams=1, first=0, order=1):
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
@@ -38,6 +38,6 @@ def reconstruct(fp, n_frames, mbs, coeffs, n_waves=1, first=0, order=1):
     yuv = np.zeros(n_mbs * 384, dtype=np.uint8)
     status = C.c_uint(0)
     st = _lib.dryv_emu_reconstruct(C.addressof(fp), n_frames, mbs.ctypes.data, coeffs.ctypes.data, yuv.ctypes.data,
-                                   C.addressof(status), n_waves, first, order)
+                                   C.addressof(status), n_teams, first, order)
     assert st == 0, st
     return int(status.value), yuv

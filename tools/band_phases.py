@@ -17,9 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dryv_amd import _build, abi, synth  # noqa: E402
 
-PHASES = ["claim+prologue", "publish", "record decode", "luma residuals", "hand-off+prefetch", "res store+top border",
-          "modes", "intra16x16", "chroma residuals", "chroma pred", "top-right copy", "intra4x4 chain",
-          "lines+left copies", "flush", "band tail", "-"]
+PHASES = ["F claim+prologue", "F record decode", "F luma residuals", "F hand-off+prefetch", "F record for BACK, modes",
+          "F chroma residuals", "F chroma pred", "F chroma lines+flush", "B wait for record", "B hand-off+top border",
+          "B intra16x16", "B top-right+publish", "B intra4x4 chain", "B line+copies+flush", "-", "-"]
 
 
 def main():
@@ -45,7 +45,7 @@ def main():
         ms = C.c_float()
         lib.dryv_recon_last_kernel_ms(h, C.byref(ms))
         tasks = n * 17
-        n_waves = min(5120, (tasks + 4) // 5 * 5)
+        n_waves = min(5120, (tasks + 4) // 5 * 10)
         out = np.zeros((n_waves, 16), dtype=np.uint64)
         assert lib.dryv_recon_debug_band_phases(h, C.c_int(n_waves), out.ctypes.data_as(C.c_void_p)) == 0
         tot = out.sum(axis=0).astype(np.float64)
@@ -53,8 +53,8 @@ def main():
         print("== %d frames: instrumented kernel %.3f ms, %d waves, %d band tasks" % (frames, ms.value, n_waves, tasks))
         for name, v in zip(PHASES, tot):
             if v > 0:
-                print("  %-24s %6.2f %%   %8.0f cycles/step" % (name, 100 * v / tot.sum(), v / steps))
-        print("  total %.0f wave-cycles/step (%.0f per macroblock)" % (tot.sum() / steps, tot.sum() / mbs.size))
+                print("  %-26s %8.0f cycles/step" % (name, v / steps))
+        print("  FRONT %.0f cycles/step, BACK %.0f cycles/step" % (tot[:8].sum() / steps, tot[8:].sum() / steps))
         lib.dryv_recon_destroy(h)
         del d_m, d_c, d_o
 
