@@ -26,6 +26,17 @@ import torch.distributed as dist
 import dryv_amd
 from dryv_amd import shard, synth
 
+def kernel_source_sha():
+    """sha256 (16 hex digits) over the sources of the kernel the bench measures: measured HBM traffic is only quoted
+    for the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("band_kernel.h", "recon_band.hip", "wave.h", "recon_kernel.hip"):
+        with open(os.path.join(ROOT, "dryv_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 ALG_BYTES_PER_MB = 1168          # 768 B coefficients + 16 B record read, 384 B pixels written (SURVEY.md §8d)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -45,10 +56,17 @@ def cpu_baseline(fp, mbs, coeffs, n_frames, gpu_out, frame_bytes, sample_frames)
            "sample": "first %d frames of the workload (%d macroblocks), oracle/dryv_oracle.c -O2, %.1f s"
                      % (k, k * per, dt),
            "gpu_output_verified_bit_exact": verified}
+    out["nproc"] = os.cpu_count()
+    out["cores_available"] = len(os.sched_getaffinity(0))
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        out["cpu_model"] = None
     # SURVEY.md 8d also asks for "all host cores, one frame per task" (frames are independent; ctypes releases the GIL)
     try:
         from concurrent.futures import ThreadPoolExecutor
-        cores = min(len(os.sched_getaffinity(0)), 16)  # (the GPU box's CPU share for one GPU)
+        cores = len(os.sched_getaffinity(0))  # every core this process may run on
         if cores > 1:
             def one(f):
                 return oracle.reconstruct(fp, 1, mbs[f * per:(f + 1) * per], coeffs[f * per:(f + 1) * per])[0]
@@ -73,6 +91,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=None)
     ap.add_argument("--cpu-sample-frames", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the per-rank oracle check of the shard's first/last frame")
     ap.add_argument("--preroll-ms", type=float, default=40.0, help="untimed device pre-roll before the warm-up steps")
     args = ap.parse_args()
 
@@ -148,17 +167,41 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # ---- every rank checks its own shard against the oracle after the timed region: the first and the last frame
+    # of the shard (bit-exact), then the per-rank verdicts, checksums and kernel times are gathered
+    verified = True
+    if not args.no_verify:
+        import oracle
+        for fidx in sorted({0, n_frames - 1}):
+            st, want = oracle.reconstruct(fp, 1, mbs[fidx * per:(fidx + 1) * per], coeffs[fidx * per:(fidx + 1) * per])
+            got = d_out[fidx * frame_bytes:(fidx + 1) * frame_bytes].cpu().numpy()
+            verified = verified and st == 0 and bool(np.array_equal(got, want))
     reports = shard.gather_reports(n_frames, n_mbs, shard.plane_checksum(d_out), ctrl, world)
     total_mbs = sum(r[1] for r in reports)
+    vt = torch.tensor([1.0 if verified else 0.0, float(np.mean(kernel_ms))], dtype=torch.float64, device=ctrl)
+    if world > 1:
+        vmin = vt.clone()
+        dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(vt, op=dist.ReduceOp.MAX)
+        all_verified, kernel_ms_max = bool(vmin[0].item() == 1.0), float(vt[1].item())
+    else:
+        all_verified, kernel_ms_max = verified, float(vt[1].item())
+    if not all_verified:
+        sys.exit("bench.py: a rank's shard differs from the oracle")
+    kernel_name = "band_kernel" if (not t8 and os.environ.get("DRYV_RECON_KERNEL", "") != "row") else "recon_kernel"
 
     if rank == 0:
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         achieved = n_mbs * ALG_BYTES_PER_MB / avg_kernel_s / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC passes of tools/profile_round.sh, quoted only when they were taken on
+        # exactly this kernel source (otherwise null: a stale figure is not a measurement of this run)
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("bytes_per_launch")
+                ent = json.load(open(tpath)).get(args.workload, {})
+                if ent.get("kernel_source_sha") == kernel_source_sha():
+                    traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
             except Exception:
                 traffic = None
         line = {
@@ -173,10 +216,13 @@ def main():
             "config": {"workload": "%s: %dx%d macroblocks x %d frames per GPU, resident in HBM; "
                                    "frames sharded contiguously, one rank per GPU, no data-path collective"
                                    % (args.workload, w, h, n_frames),
-                       "frames_per_gpu": n_frames, "macroblocks_per_step": total_mbs},
+                       "frames_per_gpu": n_frames, "macroblocks_per_step": total_mbs,
+                       "shards_verified_bit_exact": (world if not args.no_verify else 0),
+                       "shard_checksums": ["%016x" % (r[2] & 0xFFFFFFFFFFFFFFFF) for r in reports]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "recon_kernel", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name, "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_source_sha": kernel_source_sha(),
                          "algorithmic_bytes_per_launch": n_mbs * ALG_BYTES_PER_MB},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -44,7 +44,7 @@ def _run(cmd):
 
 def build_recon(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "recon_api.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("recon_kernel.h", "recon_kernel_df.inc", "band_kernel.h", "wave.h",
+    deps = srcs + [os.path.join(CSRC, f) for f in ("recon_kernel.h", "band_kernel.h", "wave.h",
                                                    "kparams.h", "recon_params.h")] + [
                    os.path.join(HERE, "..", "include", "dryv_recon.h")]
     os.makedirs(LIB, exist_ok=True)

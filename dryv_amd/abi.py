@@ -62,6 +62,7 @@ assert MB_DESC_DTYPE.itemsize == 16 and C.sizeof(MbDesc) == 16 and C.sizeof(Fram
 # every function include/dryv_recon.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "dryv_recon_frame_bytes": (C.c_size_t, [C.POINTER(FrameParams)]),
+    "dryv_recon_check_params": (C.c_int, [C.POINTER(FrameParams), C.c_uint32]),
     "dryv_recon_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "dryv_recon_destroy": (None, [C.c_void_p]),
     "dryv_recon_submit": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -38,7 +38,6 @@ struct dryv_recon_ctx {
   size_t cap_work = 0;
   int num_cus = 256;
   int grid_override = 0;
-  bool use_df = false;  // dual-frame kernel (DRYV_RECON_DF=1)
   int kernel_sel = -1;  // DRYV_RECON_KERNEL: 0 row kernel, 1 band kernel, -1 default
   // the launch in flight, kept so that a batch the fast band kernel flagged (status bit 1: a block beyond int32)
   // can be run again with the wide build before its status is reported
@@ -144,18 +143,15 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   ctx->last_band = band;
   if (band) return launch_band(ctx, P, d_mbs, d_coeffs, d_yuv, false);
   const int bpb = dryv::recon_bands_per_block();
-  const bool df = ctx->use_df;
-  const long long total_bands = df ? dryv::recon_task_count_df(P.H, P.n_frames) : (long long)P.n_frames * ((P.H + 3) / 4);
-  long long grid = ctx->grid_override > 0 ? ctx->grid_override
-                                          : (long long)ctx->num_cus * (df ? 2 : dryv::recon_blocks_per_cu());
+  const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::recon_blocks_per_cu();
   if (grid > (total_bands + bpb - 1) / bpb) grid = (total_bands + bpb - 1) / bpb;
   if (grid < 1) grid = 1;
   e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
   e = hipEventRecord(ctx->ev_start, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = df ? dryv::recon_launch_df(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream)
-         : dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
+  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "recon_kernel launch");
   e = hipEventRecord(ctx->ev_stop, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
@@ -175,6 +171,11 @@ size_t dryv_recon_frame_bytes(const dryv_frame_params* fp) {
 }
 
 int dryv_recon_abi_version(void) { return DRYV_RECON_ABI_VERSION; }
+
+int dryv_recon_check_params(const dryv_frame_params* fp, uint32_t n_frames) {
+  KParams P;
+  return build_params(fp, n_frames, &P);
+}
 
 int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
   if (!out) return DRYV_E_INVALID;
@@ -201,7 +202,6 @@ int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
       ctx->num_cus = prop.multiProcessorCount;
   }
   if (const char* s = getenv("DRYV_RECON_GRID")) ctx->grid_override = atoi(s);
-  if (const char* s = getenv("DRYV_RECON_DF")) ctx->use_df = atoi(s) != 0;
   if (const char* s = getenv("DRYV_RECON_KERNEL")) ctx->kernel_sel = strcmp(s, "band") == 0 ? 1 : strcmp(s, "row") == 0 ? 0 : -1;
   *out = ctx;
   return DRYV_OK;

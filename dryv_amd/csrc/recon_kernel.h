@@ -30,9 +30,4 @@ size_t band_profile_offset(const KParams& P);   // diagnostic builds: per-wave p
 hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
                        void* d_workspace, int grid, bool wide, hipStream_t stream);
 
-// Dual-frame kernel (each wave works on the same row of two frames): 8-wave workgroups at 4 waves per SIMD.
-long long recon_task_count_df(int H, int n_frames);
-hipError_t recon_launch_df(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv,
-                           unsigned* d_status, void* d_workspace, int grid, hipStream_t stream);
-
 }  // namespace dryv

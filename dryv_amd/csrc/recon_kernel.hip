@@ -377,101 +377,6 @@ __device__ __forceinline__ int i4_macroblock(WaveScratch* ws, int t4eAddr, const
   return M;
 }
 
-// ---- dual-frame variants: lanes 0..31 work on frame 0 of the pair, lanes 32..63 on frame 1 ---------------------------
-// Mode derivation for the frames whose macroblock is Intra4x4 (call under that lane condition). Lanes 0..15 of each
-// half = the 4x4 block grid. Returns M (derived modes); Mp = the table row per block (9 / 10 / 11: see i4_macroblock),
-// dcBlocks = this half's raster mask of DC blocks.
-template <bool INTERIOR>
-__device__ __forceinline__ int i4_modes_df(int lane, int Tb, int Lb, unsigned prevFlags, unsigned long long remBits, bool mbA,
-                                           bool mbB, bool mbC, int& MpOut, unsigned& dcBlocksOut) {
-  const int mbx = lane & 3, mby = (lane >> 2) & 3;
-  const int mzb = 8 * (mby >> 1) + 4 * (mbx >> 1) + 2 * (mby & 1) + (mbx & 1);
-  const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
-  const bool prev = ((prevFlags >> mzb) & 1u) != 0;
-  const bool unav = INTERIOR ? false : ((mbx == 0 && !mbA) || (mby == 0 && !mbB));
-  int M = 2;
-#pragma unroll
-  for (int itr = 0; itr < 7; itr++) {
-    int Am = dpp<QUAD(0, 0, 1, 2)>(M, M);
-    if (mbx == 0) Am = Lb;
-    const int Bm = dpp<ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
-    const int pm = unav ? 2 : min(Am, Bm);
-    M = prev ? pm : (rem < pm ? rem : rem + 1);
-  }
-  int Mp = M;
-  if (!INTERIOR) {
-    const bool topAv = mby > 0 || mbB, leftAv = mbx > 0 || mbA;
-    const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
-    const int req = (int)((0x217771021ull >> (4 * M)) & 7ull);
-    if ((req & ~have) != 0) Mp = 9;  // quirk Q4
-  }
-  const unsigned long long dcAll = __builtin_amdgcn_ballot_w64(Mp == 2 && (lane & 16) == 0);
-  dcBlocksOut = ((lane & 32) ? (unsigned)(dcAll >> 32) : (unsigned)dcAll) & 0xffffu;
-  {
-    const unsigned trBlocks = 0x5750u | (INTERIOR ? 0xFu : ((mbB ? 0x7u : 0u) | (mbC ? 0x8u : 0u)));
-    if (!((trBlocks >> (lane & 15)) & 1u)) Mp = Mp == 3 ? 10 : Mp == 7 ? 11 : Mp;
-  }
-  MpOut = Mp;
-  return M;
-}
-
-// Entry + residual packing for frame hh of the pair: all 64 lanes (block g, column sq), like i4_macroblock.
-__device__ __forceinline__ void i4_pack_df(WaveScratch* ws, int t4eAddr, const int rl[4], int lane, int MpP, int hh) {
-  const int sq = lane & 3, sb = lane >> 2;
-  const int sbx = ((sb >> 1) & 2) | (sb & 1), sby = ((sb >> 2) & 2) | ((sb >> 1) & 1);
-  const int g = sby * 4 + sbx;
-  const int mode = shfl(MpP, 32 * hh + g);
-  const u32x4 te = *LDSP(lds_u4p, t4eAddr + mode * 64 + sq * 16);
-  *(u32x4*)&ws->resTe[g * 16 + sq * 4] = te;
-  const int r0 = min(max(rl[0], -512), 511), r1 = min(max(rl[1], -512), 511);
-  const int r2 = min(max(rl[2], -512), 511), r3 = min(max(rl[3], -512), 511);
-  uint2 rp;
-  rp.x = __builtin_amdgcn_perm((unsigned)r1, (unsigned)r0, 0x05040100u);
-  rp.y = __builtin_amdgcn_perm((unsigned)r3, (unsigned)r2, 0x05040100u);
-  *(uint2*)&ws->resS[g * 16 + sq * 4] = rp;
-}
-
-// The 10-step pixel wavefront for the frames whose macroblock is Intra4x4 (call under that lane condition):
-// 32 lanes per frame, each with its own scratch (wsAddrL).
-template <bool INTERIOR>
-__device__ __forceinline__ void i4_chain_df(int wsAddrL, int lane, unsigned dcBlocks, bool mbA, bool mbB) {
-  I4Lane L;
-  {
-    const int li = lane & 15, g = (lane >> 4) & 1;
-    const int px = li & 3, py = li >> 2;
-    const int tileBase = wsAddrL + (int)offsetof(WaveScratch, tileY);
-    const int rtBase = wsAddrL + (int)offsetof(WaveScratch, resTe);
-    const int rsBase = wsAddrL + (int)offsetof(WaveScratch, resS);
-    L.pS = tileBase - 33 + 120 * g;
-    L.pW = tileBase + py * 32 + px + 120 * g;
-    L.pEnt = rtBase + 4 * (px * 4 + py) + 128 * g;
-    L.pRes = rsBase + 2 * (px * 4 + py) + 64 * g;
-    L.grp1 = g != 0;
-  }
-  unsigned e;
-  int r;
-  i4_fetch<0>(L, e, r);
-  i4_step<0, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<1, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<2, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<3, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<4, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<5, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<6, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<7, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<8, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-  WAVE_SYNC();
-  i4_step<9, INTERIOR>(L, e, r, dcBlocks, mbA, mbB);
-}
-
 // relaxed agent-scope accesses: global_load/store ... sc1 (served by / written through L2, bypassing L1)
 __device__ __forceinline__ unsigned ld_sc1(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -503,14 +408,14 @@ __device__ __forceinline__ void dma_coefficients(int ldsAddr, unsigned voff, i32
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
                : "s"(ldsAddr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");
+               : "memory", "m0");
 }
 
 // one dword per active lane from a per-lane global address, write-through-coherent (sc1), to LDS ldsAddr + 4*lane;
 // hidden from the compiler for the same reason (and because a conditionally issued VGPR load leaves its
 // destination "possibly pending" in hipcc's scoreboard, which then waits vmcnt(0) before reusing that register)
 __device__ __forceinline__ void dma_window(int ldsAddr, const unsigned* src) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1" : : "s"(ldsAddr), "v"(src) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1" : : "s"(ldsAddr), "v"(src) : "memory", "m0");
 }
 
 #define BAND 4     // rows per band = waves that hand rows to each other through LDS
@@ -1256,23 +1161,8 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
 #endif
 }
 
-// ---- dual-frame variant: every wave works on the same row of TWO frames ---------------------------
-struct BandSharedDF {
-  unsigned prog[BAND];
-  unsigned cons[BAND];
-  unsigned task, seq, arrive, pad;
-  uint8_t ringY[2][BAND][RING_K * 16];
-  uint8_t ringC[2][BAND][2][RING_K * 8];
-  unsigned ringM[2][BAND][RING_K];
-};
-
-#include "recon_kernel_df.inc"
-
 int recon_bands_per_block() { return WG_BANDS; }
 int recon_blocks_per_cu() { return DRYV_WPS * 4 / (BAND * WG_BANDS); }
-
-size_t recon_lds_bytes_df() { return LT_END + (size_t)2 * WG_BANDS * BAND * sizeof(WaveScratch) + WG_BANDS * sizeof(BandSharedDF); }
-long long recon_task_count_df(int H, int n_frames) { return (long long)((n_frames + 1) / 2) * ((H + BAND - 1) / BAND); }
 
 size_t recon_lds_bytes() { return LT_END + (size_t)WG_BANDS * BAND * sizeof(WaveScratch) + WG_BANDS * sizeof(BandShared); }
 
@@ -1301,27 +1191,6 @@ hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeff
   const size_t ldsBytes = recon_lds_bytes();
   unsigned char* wsb = (unsigned char*)d_workspace;
   hipLaunchKernelGGL(recon_kernel, dim3(grid), dim3(wavesPerBlock * 64), ldsBytes, stream, P,
-                     (const dryv_mb_desc*)d_mbs, (const int16_t*)d_coeffs, (uint8_t*)d_yuv, d_status,
-                     (unsigned*)(wsb + 256), (unsigned*)(wsb + 256 + prog_bytes(P)), (unsigned*)wsb
-#ifdef DRYV_PHASE_PROFILE
-                     , (unsigned long long*)(wsb + (((256 + prog_bytes(P) + (size_t)P.n_frames * P.W * P.H * 4) + 255) & ~(size_t)255))
-#endif
-                     );
-  return hipGetLastError();
-}
-
-
-hipError_t recon_launch_df(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                           void* d_workspace, int grid, hipStream_t stream) {
-  const int wavesPerBlock = BAND * WG_BANDS;
-  const size_t ldsBytes = recon_lds_bytes_df();
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)recon_kernel_df, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-    attr = true;
-  }
-  unsigned char* wsb = (unsigned char*)d_workspace;
-  hipLaunchKernelGGL(recon_kernel_df, dim3(grid), dim3(wavesPerBlock * 64), ldsBytes, stream, P,
                      (const dryv_mb_desc*)d_mbs, (const int16_t*)d_coeffs, (uint8_t*)d_yuv, d_status,
                      (unsigned*)(wsb + 256), (unsigned*)(wsb + 256 + prog_bytes(P)), (unsigned*)wsb
 #ifdef DRYV_PHASE_PROFILE

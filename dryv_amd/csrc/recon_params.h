@@ -76,6 +76,11 @@ inline void build_pred_table(int n, uint8_t* t) {
 inline int build_params(const dryv_frame_params* fp, uint32_t n_frames, KParams* P) {
   if (!fp) return DRYV_E_INVALID;
   if (fp->pic_width_in_mbs == 0 || fp->pic_height_in_mbs == 0 || fp->pic_width_in_mbs > 1024) return DRYV_E_INVALID;
+  // the kernels address a frame's planes, records and coefficients with 32-bit byte offsets (768 B of coefficients per
+  // macroblock is the largest) and count the batch's macroblocks in 31 bits
+  const unsigned long long per = (unsigned long long)fp->pic_width_in_mbs * fp->pic_height_in_mbs;
+  if (per * 768ull > 0xFFFFFFFFull) return DRYV_E_INVALID;
+  if (n_frames == 0 || per * (unsigned long long)n_frames > 0x7FFFFFFFull) return DRYV_E_INVALID;
   if (fp->chroma_array_type != 1 || fp->bit_depth_y != 8 || fp->bit_depth_c != 8) return DRYV_E_UNSUPPORTED;
   memset(P, 0, sizeof(*P));
   P->W = fp->pic_width_in_mbs;

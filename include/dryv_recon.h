@@ -95,6 +95,11 @@ typedef struct dryv_mb_desc {
  * cropping; frames concatenated. */
 size_t dryv_recon_frame_bytes(const dryv_frame_params *fp); /* 384 * W * H, 0 if fp invalid */
 
+/* Validates a parameter block / batch size without touching a device: DRYV_OK, DRYV_E_UNSUPPORTED (outside the
+ * reference's domain: see above) or DRYV_E_INVALID (zero-sized picture, width > 1024 macroblocks, a frame whose
+ * coefficients exceed 4 GB, a batch of 2^31 macroblocks or more, n_frames == 0). submit applies the same checks. */
+int dryv_recon_check_params(const dryv_frame_params *fp, uint32_t n_frames);
+
 typedef struct dryv_recon_ctx dryv_recon_ctx;
 
 /* Opens HIP device `device_ordinal`, creates the stream, events and status words. Fails with

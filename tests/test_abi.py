@@ -102,3 +102,21 @@ def test_product_does_not_reference_the_oracle():
     assert "dryv_oracle" not in syms
     needed = subprocess.check_output(["readelf", "-d", _build.RECON_SO], text=True)
     assert "oracle" not in needed
+
+
+def test_parameter_bounds_are_checked_without_a_device():
+    """The kernels use 32-bit offsets inside a frame and 31-bit macroblock counts; anything beyond must be refused by
+    the boundary, not wrapped on the device (round-1 finding: H was unbounded)."""
+    lib = abi.load_library()
+    ok = abi.make_frame_params(120, 68)
+    assert lib.dryv_recon_check_params(ok, 300) == abi.DRYV_OK
+    assert lib.dryv_recon_check_params(ok, 0) == abi.DRYV_E_INVALID
+    assert lib.dryv_recon_check_params(abi.make_frame_params(1024, 5461), 1) == abi.DRYV_OK        # 4,294,574,080 B? no: just under
+    assert lib.dryv_recon_check_params(abi.make_frame_params(1024, 5462), 1) == abi.DRYV_E_INVALID   # 768 B/MB x W x H >= 2^32
+    assert lib.dryv_recon_check_params(abi.make_frame_params(1024, 20000), 1) == abi.DRYV_E_INVALID
+    assert lib.dryv_recon_check_params(abi.make_frame_params(1025, 4), 1) == abi.DRYV_E_INVALID
+    assert lib.dryv_recon_check_params(ok, 263172) == abi.DRYV_OK          # 8160 x 263172 = 2^31 - 4,288 macroblocks
+    assert lib.dryv_recon_check_params(ok, 263173) == abi.DRYV_E_INVALID   # >= 2^31
+    bad = abi.make_frame_params(4, 4)
+    bad.bit_depth_y = 10
+    assert lib.dryv_recon_check_params(bad, 1) == abi.DRYV_E_UNSUPPORTED

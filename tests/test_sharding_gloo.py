@@ -79,3 +79,53 @@ def test_two_rank_control_plane_gloo():
     fp = abi.make_frame_params(6, 4, cqo_cb=2, transform_8x8=True)
     whole, _ = synth.generate(fp, synth.config(i4x4=0.5, i8x8=0.2), 4, 0, 5)
     assert m0 + m1 == whole.tobytes()                          # shards tile the batch exactly
+
+
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    if rank == 0:
+        fp = abi.make_frame_params(120, 68)
+        table = shard.partition_frames(2400, world)          # BASELINE.json configs[3]: 300 frames per GPU
+    else:
+        fp, table = abi.make_frame_params(1, 1), None
+    fp, table = shard.broadcast_control(fp, table, dev, rank, world)
+    first, n = table[rank]
+    # one frame of the shard stands in for the planes (the CPU test has no GPU to reconstruct 300)
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.7, i8x8=0.0), 2, first, 1)
+    planes = torch.from_numpy((co.reshape(-1)[: 8160 * 384] & 0xFF).astype(np.uint8))
+    reports = shard.gather_reports(n, n * 8160, shard.plane_checksum(planes), dev, world)
+    # the same reductions bench.py uses for the verified flag and the kernel time
+    vt = torch.tensor([1.0, 2.0 + 0.01 * rank], dtype=torch.float64)
+    vmin = vt.clone()
+    dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(vt, op=dist.ReduceOp.MAX)
+    q.put((rank, table, reports, float(vmin[0]), float(vt[1]), shard.plane_checksum(planes)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_control_plane_gloo():
+    """The control plane of the 8-GPU configuration (2400 frames -> 8 x 300) with eight gloo ranks on the CPU."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    want_table = [(i * 300, 300) for i in range(8)]
+    sums = [r[5] for r in res]
+    for rank, table, reports, vmin, kmax, _ in res:
+        assert table == want_table
+        assert [r[0] for r in reports] == [300] * 8 and [r[1] for r in reports] == [300 * 8160] * 8
+        assert [r[2] for r in reports] == sums            # every rank sees every rank's checksum
+        assert vmin == 1.0 and abs(kmax - 2.07) < 1e-9
+    assert len(set(sums)) == 8                            # different frames on every rank
