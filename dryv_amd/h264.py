@@ -1,0 +1,83 @@
+"""ctypes view of libdryv_h264.so — the host producer: mp4 / Annex-B demux + SPS/PPS/slice header +
+I-slice CABAC parse into the batch the reconstruction ABI takes, and the CABAC I-slice encoder that writes synthetic
+batches as real Annex-B streams. Host code only; nothing here touches a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build, abi
+
+SO = os.path.join(_build.LIB, "libdryv_h264.so")
+_lib = None
+
+
+def build(force=False):
+    host = os.path.join(_build.HERE, "host")
+    srcs = [os.path.join(host, f) for f in ("h264_capi.cpp", "h264_islice.hpp", "cabac_tables.inc")]
+    os.makedirs(_build.LIB, exist_ok=True)
+    if force or _build._stale(SO, srcs + [os.path.join(_build.HERE, "..", "include", "dryv_recon.h")]):
+        _build._run(["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", "-o", SO, srcs[0]])
+    return SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.dryv_h264_parse.restype = C.c_void_p
+        _lib.dryv_h264_parse.argtypes = [C.c_void_p, C.c_size_t]
+        _lib.dryv_h264_last_error.restype = C.c_char_p
+        _lib.dryv_h264_free.argtypes = [C.c_void_p]
+        for n in ("dryv_h264_params", "dryv_h264_mbs", "dryv_h264_coeffs"):
+            getattr(_lib, n).restype = C.c_void_p
+            getattr(_lib, n).argtypes = [C.c_void_p]
+        _lib.dryv_h264_info.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.dryv_h264_encode_idr.restype = C.c_longlong
+        _lib.dryv_h264_encode_idr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    return _lib
+
+
+class H264Error(RuntimeError):
+    pass
+
+
+def parse_first_islice(data):
+    """data: bytes of an .mp4 (ISO-BMFF, avc1) or Annex-B stream. Returns (fp, mbs, coeffs, info)."""
+    lib = _load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    h = lib.dryv_h264_parse(buf.ctypes.data, buf.size)
+    if not h:
+        raise H264Error(lib.dryv_h264_last_error().decode())
+    try:
+        fp = abi.FrameParams()
+        C.memmove(C.addressof(fp), lib.dryv_h264_params(h), C.sizeof(fp))
+        n = fp.pic_width_in_mbs * fp.pic_height_in_mbs
+        mbs = np.empty(n, dtype=abi.MB_DESC_DTYPE)
+        C.memmove(mbs.ctypes.data, lib.dryv_h264_mbs(h), n * 16)
+        coeffs = np.empty((n, 384), dtype=np.int16)
+        C.memmove(coeffs.ctypes.data, lib.dryv_h264_coeffs(h), n * 768)
+        info = np.zeros(8, dtype=np.int64)
+        lib.dryv_h264_info(h, info.ctypes.data)
+    finally:
+        lib.dryv_h264_free(h)
+    keys = ("bins", "slice_bytes", "bits_unread", "tail_ok", "n_i4x4", "n_i8x8", "n_i16x16", "slice_qp")
+    return fp, mbs, coeffs, dict(zip(keys, (int(v) for v in info)))
+
+
+def encode_idr(fp, mbs, coeffs, slice_qp=26):
+    """One picture (flat scaling lists) -> Annex-B bytes (SPS, PPS, IDR I slice, CABAC)."""
+    lib = _load()
+    mbs = np.ascontiguousarray(mbs)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    n = fp.pic_width_in_mbs * fp.pic_height_in_mbs
+    assert mbs.size == n and coeffs.size == n * 384
+    cap = 64 + n * 1200
+    out = np.empty(cap, dtype=np.uint8)
+    r = lib.dryv_h264_encode_idr(C.addressof(fp), mbs.ctypes.data, coeffs.ctypes.data, slice_qp, out.ctypes.data, cap)
+    if r < 0:
+        out = np.empty(-r, dtype=np.uint8)
+        r = lib.dryv_h264_encode_idr(C.addressof(fp), mbs.ctypes.data, coeffs.ctypes.data, slice_qp, out.ctypes.data, out.size)
+    if r <= 0:
+        raise H264Error(lib.dryv_h264_last_error().decode())
+    return out[:r].tobytes()

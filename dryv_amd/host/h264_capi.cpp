@@ -1,0 +1,60 @@
+// h264_capi.cpp — C ABI over h264_islice.hpp (libdryv_h264.so, host only): the host producer of SURVEY.md 8(f)-1.
+#include "h264_islice.hpp"
+
+#include <stdlib.h>
+
+using namespace dryv::h264;
+
+extern "C" {
+
+struct dryv_h264_frame {
+  ParsedFrame F;
+  std::string err;
+};
+
+/* Parses the first coded picture (an I slice) of an .mp4 / Annex-B buffer. Returns NULL on failure (message via
+ * dryv_h264_last_error). */
+static thread_local std::string g_err;
+dryv_h264_frame* dryv_h264_parse(const uint8_t* data, size_t n) {
+  try {
+    dryv_h264_frame* h = new dryv_h264_frame();
+    h->F = parse_first_islice(data, n);
+    return h;
+  } catch (const Error& e) {
+    g_err = e.what;
+    return nullptr;
+  }
+}
+const char* dryv_h264_last_error(void) { return g_err.c_str(); }
+void dryv_h264_free(dryv_h264_frame* h) { delete h; }
+const dryv_frame_params* dryv_h264_params(const dryv_h264_frame* h) { return &h->F.fp; }
+const dryv_mb_desc* dryv_h264_mbs(const dryv_h264_frame* h) { return h->F.mbs.data(); }
+const int16_t* dryv_h264_coeffs(const dryv_h264_frame* h) { return h->F.coeffs.data(); }
+/* info[0..7] = bins decoded, slice NAL bytes, bits left unread, tail ok, Intra4x4 / Intra8x8 / Intra16x16 counts, slice qp */
+void dryv_h264_info(const dryv_h264_frame* h, long long* info) {
+  info[0] = h->F.bins;
+  info[1] = (long long)h->F.slice_bytes;
+  info[2] = (long long)h->F.bits_unread;
+  info[3] = h->F.tail_ok ? 1 : 0;
+  info[4] = h->F.kinds[0];
+  info[5] = h->F.kinds[1];
+  info[6] = h->F.kinds[2];
+  info[7] = h->F.slice_qp;
+}
+
+/* Encodes one picture (flat scaling lists) as an Annex-B stream: SPS, PPS, one IDR I slice. Returns the byte count, or
+ * 0 on failure / when `cap` is too small (call with cap = 0 to size the buffer: returns the needed size negated). */
+long long dryv_h264_encode_idr(const dryv_frame_params* fp, const dryv_mb_desc* mbs, const int16_t* coeffs, int slice_qp,
+                               uint8_t* out, size_t cap) {
+  try {
+    const std::vector<uint8_t> v = encode_idr_annexb(*fp, mbs, coeffs, slice_qp);
+    if (v.size() > cap) return -(long long)v.size();
+    memcpy(out, v.data(), v.size());
+    return (long long)v.size();
+  } catch (const Error& e) {
+    g_err = e.what;
+    return 0;
+  }
+}
+
+}  // extern "C"
