@@ -69,7 +69,7 @@ HARNESS = os.path.join(LIB, "frame_harness")
 def build_harness(force=False):
     """C++ host mirror of the reference's Frame interface (host/frame.hpp) + its harness binary."""
     host = os.path.join(HERE, "host")
-    srcs = [os.path.join(host, "frame_harness.cpp"), os.path.join(host, "frame.hpp")]
+    srcs = [os.path.join(host, f) for f in ("frame_harness.cpp", "frame.hpp", "h264_islice.hpp", "cabac_tables.inc")]
     build_recon(force)
     if force or _stale(HARNESS, srcs + [RECON_SO]):
         _run(["g++", "-O2", "-std=c++17", "-Wall", "-o", HARNESS, srcs[0], "-L" + LIB, "-ldryv_recon",
@@ -77,8 +77,13 @@ def build_harness(force=False):
     return HARNESS
 
 
+def build_h264(force=False):
+    from . import h264
+    return h264.build(force)
+
+
 def build_all(force=False):
-    return [build_recon(force), build_synth(force), build_harness(force)]
+    return [build_recon(force), build_synth(force), build_harness(force), build_h264(force)]
 
 
 if __name__ == "__main__":

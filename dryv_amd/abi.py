@@ -67,6 +67,10 @@ SYMBOLS = {
     "dryv_recon_destroy": (None, [C.c_void_p]),
     "dryv_recon_submit": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.c_void_p]),
     "dryv_recon_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dryv_recon_submit_host": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t]),
+    "dryv_recon_alloc_host": (C.c_void_p, [C.c_size_t]),
+    "dryv_recon_free_host": (None, [C.c_void_p]),
     "dryv_recon_submit_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     "dryv_recon_sync": (C.c_int, [C.c_void_p]),

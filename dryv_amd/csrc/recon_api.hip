@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <string>
+#include <vector>
 
 #include "recon_kernel.h"
 #include "recon_params.h"
@@ -47,6 +48,13 @@ struct dryv_recon_ctx {
   void* last_yuv = nullptr;
   bool last_band = false;
   int wide_reruns = 0;
+  // pipelined host path (dryv_recon_submit_host): copy-in and copy-out streams, per-chunk events
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  std::vector<hipEvent_t> ev_in, ev_k;
+  bool piped = false;          // the batch in flight was submitted with dryv_recon_submit_host
+  const dryv_mb_desc* piped_mbs = nullptr;
+  const int16_t* piped_coeffs = nullptr;
+  uint8_t* piped_out = nullptr;
   std::string last_error;
 };
 
@@ -104,11 +112,51 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   return DRYV_OK;
 }
 
+
+// One chunk of a pipelined host submit: workspace reset + kernel on the compute stream; status accumulates over the
+// chunks (it is cleared once per submit), no events.
+int launch_chunk(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv) {
+  hipError_t e;
+  const bool band = ctx->kernel_sel == 1 || (ctx->kernel_sel < 0 && !P.transform8x8);
+  ctx->last_band = band;
+  if (band) {
+    const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
+    const int wpb = dryv::band_teams_per_block();
+    long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
+    grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
+    if ((e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+    e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, ctx->stream);
+    return e == hipSuccess ? DRYV_OK : fail(ctx, e, "band_kernel launch");
+  }
+  const int bpb = dryv::recon_bands_per_block();
+  const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::recon_blocks_per_cu();
+  grid = std::max(1ll, std::min(grid, (total_bands + bpb - 1) / bpb));
+  if ((e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
+  return e == hipSuccess ? DRYV_OK : fail(ctx, e, "recon_kernel launch");
+}
+
 // Waits for the launch in flight. A batch the fast band kernel flagged as needing 64-bit arithmetic is run again with
 // the wide build (same buffers; the caller's inputs are still valid: they must be until wait/sync returns).
 int finish(dryv_recon_ctx* ctx) {
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
+  if (ctx->piped) {
+    ctx->piped = false;
+    if ((e = hipStreamSynchronize(ctx->s_out)) != hipSuccess) return fail(ctx, e, "hipStreamSynchronize(copy-out)");
+    if (ctx->last_band && (*ctx->h_status & 2u)) {
+      // a block beyond int32: the whole batch again, unpipelined, with the wide build (never for a conformant stream)
+      ctx->wide_reruns++;
+      const KParams& P = ctx->last_P;
+      if ((e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
+      int st = launch_band(ctx, P, ctx->d_mbs, ctx->d_coeffs, ctx->d_yuv, true);
+      if (st != DRYV_OK) return st;
+      e = hipMemcpyAsync(ctx->piped_out, ctx->d_yuv, (size_t)P.n_frames * P.W * P.H * 384, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) return fail(ctx, e, "wide re-run");
+    }
+  } else
   if (ctx->last_band && (*ctx->h_status & 2u)) {
     ctx->wide_reruns++;
     e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
@@ -219,6 +267,10 @@ void dryv_recon_destroy(dryv_recon_ctx* ctx) {
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  for (hipEvent_t ev : ctx->ev_in) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->ev_k) (void)hipEventDestroy(ev);
+  if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
+  if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -265,6 +317,83 @@ int dryv_recon_wait(dryv_recon_ctx* ctx, uint8_t* yuv_out, size_t yuv_out_bytes)
   if (st != DRYV_OK) return st;
   if (e != hipSuccess) return fail(ctx, e, "D2H planes");
   return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;
+}
+
+
+/* ---- pinned host memory + pipelined host-buffer path ---------------------------------------------- */
+void* dryv_recon_alloc_host(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void dryv_recon_free_host(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int dryv_recon_submit_host(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const dryv_mb_desc* mbs,
+                           const int16_t* coeffs, uint8_t* yuv_out, size_t yuv_out_bytes) {
+  if (!ctx || !mbs || !coeffs || !yuv_out || n_frames == 0) return DRYV_E_INVALID;
+  if (ctx->in_flight) return DRYV_E_STATE;
+  KParams P;
+  int st = build_params(fp, n_frames, &P);
+  if (st != DRYV_OK) return st;
+  (void)hipSetDevice(ctx->device);
+  const size_t per = (size_t)P.W * P.H, n_mbs = per * n_frames;
+  if (yuv_out_bytes < n_mbs * 384) return DRYV_E_INVALID;
+  if ((st = ensure(ctx, &ctx->d_mbs, &ctx->cap_mbs, n_mbs * sizeof(dryv_mb_desc))) != DRYV_OK) return st;
+  if ((st = ensure(ctx, &ctx->d_coeffs, &ctx->cap_coeffs, n_mbs * 768)) != DRYV_OK) return st;
+  if ((st = ensure(ctx, &ctx->d_yuv, &ctx->cap_yuv, n_mbs * 384)) != DRYV_OK) return st;
+  hipError_t e;
+  if (!ctx->s_in && ((e = hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking)) != hipSuccess ||
+                     (e = hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking)) != hipSuccess))
+    return fail(ctx, e, "hipStreamCreate");
+  // Chunks of frames: copy-in of chunk k+1, reconstruction of chunk k and copy-out of chunk k-1 overlap on three
+  // streams. A chunk's kernel cannot be shorter than one frame's dependency chain (about a millisecond), so chunks
+  // are sized for a copy-in of a few milliseconds: ~128 MB of coefficients.
+  uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)128 << 20) / (per * 768));
+  if (const char* sv = getenv("DRYV_RECON_CHUNK_FRAMES")) chunk = (uint32_t)std::max(1, atoi(sv));
+  const uint32_t n_chunks = (n_frames + chunk - 1) / chunk;
+  while (ctx->ev_in.size() < n_chunks) {
+    hipEvent_t a, b;
+    if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess)
+      return fail(ctx, e, "hipEventCreate");
+    ctx->ev_in.push_back(a);
+    ctx->ev_k.push_back(b);
+  }
+  if ((e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
+  st = ensure(ctx, &ctx->d_work, &ctx->cap_work, workspace_bytes(P));
+  if (st != DRYV_OK) return st;
+  if ((e = hipEventRecord(ctx->ev_start, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  for (uint32_t k = 0; k < n_chunks; k++) {
+    const uint32_t f0 = k * chunk, nf = std::min(chunk, n_frames - f0);
+    const size_t m0 = (size_t)f0 * per, nm = (size_t)nf * per;
+    if ((e = hipMemcpyAsync((char*)ctx->d_mbs + m0 * 16, mbs + m0, nm * 16, hipMemcpyHostToDevice, ctx->s_in)) != hipSuccess ||
+        (e = hipMemcpyAsync((char*)ctx->d_coeffs + m0 * 768, coeffs + m0 * 384, nm * 768, hipMemcpyHostToDevice, ctx->s_in)) != hipSuccess ||
+        (e = hipEventRecord(ctx->ev_in[k], ctx->s_in)) != hipSuccess ||
+        (e = hipStreamWaitEvent(ctx->stream, ctx->ev_in[k], 0)) != hipSuccess)
+      return fail(ctx, e, "chunk copy-in");
+    KParams Pk = P;
+    Pk.n_frames = (int)nf;
+    st = launch_chunk(ctx, Pk, (char*)ctx->d_mbs + m0 * 16, (char*)ctx->d_coeffs + m0 * 768, (char*)ctx->d_yuv + m0 * 384);
+    if (st != DRYV_OK) return st;
+    if ((e = hipEventRecord(ctx->ev_k[k], ctx->stream)) != hipSuccess ||
+        (e = hipStreamWaitEvent(ctx->s_out, ctx->ev_k[k], 0)) != hipSuccess ||
+        (e = hipMemcpyAsync(yuv_out + m0 * 384, (char*)ctx->d_yuv + m0 * 384, nm * 384, hipMemcpyDeviceToHost, ctx->s_out)) != hipSuccess)
+      return fail(ctx, e, "chunk copy-out");
+  }
+  if ((e = hipEventRecord(ctx->ev_stop, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  if ((e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+    return fail(ctx, e, "hipMemcpyAsync(status)");
+  ctx->timed = true;
+  ctx->last_P = P;
+  ctx->piped = true;
+  ctx->piped_mbs = mbs;
+  ctx->piped_coeffs = coeffs;
+  ctx->piped_out = yuv_out;
+  ctx->in_flight = true;
+  ctx->in_flight_host = false;
+  return DRYV_OK;
 }
 
 int dryv_recon_submit_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const void* d_mbs,

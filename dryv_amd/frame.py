@@ -94,6 +94,33 @@ class ReconContext:
         return self.wait(allow_unsupported=allow_unsupported)
 
     # ---- device-resident path ---------------------------------------------------------------
+    def alloc_host(self, shape, dtype):
+        """A page-locked numpy array (dryv_recon_alloc_host): the memory the pipelined host path copies at PCIe speed
+        from / to. Free with free_host(array) (or leave it to process exit)."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = self._lib.dryv_recon_alloc_host(max(n, 1))
+        if not p:
+            raise ReconError(abi.DRYV_E_NOMEM)
+        buf = (C.c_uint8 * n).from_address(p)
+        arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def free_host(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self._lib.dryv_recon_free_host(p)
+
+    def submit_host(self, fp, n_frames, mbs, coeffs, yuv_out):
+        """dryv_recon_submit_host: chunked, three-stream pipelined host path; completes at sync()."""
+        mbs = np.ascontiguousarray(mbs)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+        self._keep = (mbs, coeffs, yuv_out)
+        _check(self._lib.dryv_recon_submit_host(self._h, C.byref(fp), int(n_frames), mbs.ctypes.data, coeffs.ctypes.data,
+                                                yuv_out.ctypes.data, yuv_out.nbytes), self._h)
+
     def submit_device(self, fp, n_frames, d_mbs, d_coeffs, d_yuv_out):
         """All three are raw device pointers (ints), e.g. torch_tensor.data_ptr()."""
         _check(self._lib.dryv_recon_submit_device(self._h, C.byref(fp), int(n_frames), C.c_void_p(d_mbs),

@@ -4,11 +4,19 @@
 //   frame_harness <in.batch> <out.yuv>
 // in.batch: dryv_frame_params (496 B) | u32 n_frames | dryv_mb_desc[n] | int16 coeffs[n][384]
 // (written by tests/test_host_harness.py from the synthetic generator). Frames are written back to back.
+//
+//   frame_harness decode <in.mp4 | in.h264> <out.yuv>
+// BASELINE.json configs[0], end to end: what `dryv <path>` does for its one decoded picture (video/decoder.rs:88-143:
+// sample 0 of the video track -> slice NAL -> CABAC macroblock loop -> Frame::decode per macroblock ->
+// write_to_yuv_file("temp/yuv_frame")), with the entropy decoding on the host (h264_islice.hpp) and the reconstruction
+// behind the C ABI. Prints one line of parse statistics.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "frame.hpp"
+#include "h264_islice.hpp"
 
 static dryv::Macroblock unpack(const dryv_mb_desc& d, const int16_t* c) {
   dryv::Macroblock mb;
@@ -40,7 +48,42 @@ static dryv::Macroblock unpack(const dryv_mb_desc& d, const int16_t* c) {
   return mb;
 }
 
+static int decode_file(const char* in, const char* outp) {
+  FILE* f = std::fopen(in, "rb");
+  if (!f) { std::perror("open"); return 2; }
+  std::vector<uint8_t> data;
+  uint8_t buf[65536];
+  size_t k;
+  while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
+  std::fclose(f);
+  dryv::h264::ParsedFrame P;
+  try {
+    P = dryv::h264::parse_first_islice(data.data(), data.size());
+  } catch (const dryv::h264::Error& e) {
+    std::fprintf(stderr, "parse: %s\n", e.what.c_str());
+    return 6;
+  }
+  const size_t per = (size_t)P.fp.pic_width_in_mbs * P.fp.pic_height_in_mbs;
+  std::printf("parsed %ux%u macroblocks: %d Intra4x4 %d Intra8x8 %d Intra16x16, slice qp %d, %ld bins, %zu bytes, tail %s\n",
+              P.fp.pic_width_in_mbs, P.fp.pic_height_in_mbs, P.kinds[0], P.kinds[1], P.kinds[2], P.slice_qp, P.bins,
+              P.slice_bytes, P.tail_ok ? "ok" : "BAD");
+  if (!P.tail_ok) return 6;
+  dryv_recon_ctx* ctx = nullptr;
+  int st = dryv_recon_create(&ctx, 0);
+  if (st != DRYV_OK) { std::fprintf(stderr, "dryv_recon_create: %s\n", dryv_recon_strerror(st)); return 3; }
+  dryv::Frame frame(P.fp, ctx);                                       // Frame::new(&slice)      decoder.rs:124
+  for (size_t a = 0; a < per; a++) {                                  // cabac/mod.rs:208
+    st = frame.decode(unpack(P.mbs[a], &P.coeffs[a * DRYV_COEFFS_PER_MB]));
+    if (st != DRYV_OK) { std::fprintf(stderr, "decode: %s\n", dryv_recon_strerror(st)); return 4; }
+  }
+  st = frame.write_to_yuv_file(outp);                                 // decoder.rs:142
+  if (st != DRYV_OK) { std::fprintf(stderr, "reconstruct: %s\n", dryv_recon_strerror(st)); return 5; }
+  dryv_recon_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4 && std::strcmp(argv[1], "decode") == 0) return decode_file(argv[2], argv[3]);
   if (argc != 3) { std::fprintf(stderr, "usage: %s in.batch out.yuv\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("open"); return 2; }

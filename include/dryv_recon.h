@@ -117,6 +117,17 @@ int dryv_recon_submit(dryv_recon_ctx *ctx, const dryv_frame_params *fp, uint32_t
  * affected macroblocks are then left zero-filled, like an undecoded Frame). */
 int dryv_recon_wait(dryv_recon_ctx *ctx, uint8_t *yuv_out, size_t yuv_out_bytes);
 
+/* Pipelined host-buffer path (what a dryv process that decodes many pictures should call): the batch is cut into
+ * chunks of frames, and copy-in of chunk k+1, reconstruction of chunk k and copy-out of chunk k-1 overlap on three
+ * streams; the planes land directly in yuv_out (n_frames * dryv_recon_frame_bytes() bytes). Asynchronous: pair with
+ * dryv_recon_sync; all four buffers must stay valid and untouched until it returns. The copies only run at PCIe speed,
+ * and only overlap, from page-locked memory: allocate the buffers with dryv_recon_alloc_host (or hipHostRegister
+ * them); pageable buffers work but are staged by the driver. */
+int dryv_recon_submit_host(dryv_recon_ctx *ctx, const dryv_frame_params *fp, uint32_t n_frames,
+                           const dryv_mb_desc *mbs, const int16_t *coeffs, uint8_t *yuv_out, size_t yuv_out_bytes);
+void *dryv_recon_alloc_host(size_t bytes); /* page-locked host memory (hipHostMalloc); NULL on failure */
+void dryv_recon_free_host(void *p);
+
 /* Device-resident path: all three buffers already live in this device's HBM (device pointers).
  * Nothing is copied; the planes are written straight into d_yuv_out. Asynchronous on the
  * context's stream; pair with dryv_recon_sync. */

@@ -369,3 +369,50 @@ def test_full_batch_properties_c3(recon_ctx):
     idx = (perm[:, None] * per + np.arange(per)[None, :]).ravel()
     out3 = recon_ctx.reconstruct(fp, n, mbs[idx], co[idx])
     assert np.array_equal(out3.reshape(n, fb), out1.reshape(n, fb)[perm])
+
+
+def test_pipelined_host_path_chunk_boundaries(recon_ctx):
+    """dryv_recon_submit_host: chunks of frames on three streams (copy-in, reconstruction, copy-out), page-locked and
+    pageable buffers, chunk sizes that do and do not divide the batch -- always the oracle's planes."""
+    fp = abi.make_frame_params(23, 11)
+    frames = 13
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0), 77, 0, frames)
+    st, want = oracle.reconstruct(fp, frames, mbs, co)
+    assert st == 0
+    pm = recon_ctx.alloc_host(mbs.shape, mbs.dtype)
+    pc = recon_ctx.alloc_host(co.shape, co.dtype)
+    po = recon_ctx.alloc_host(want.shape, np.uint8)
+    pm[...] = mbs
+    pc[...] = co
+    try:
+        for chunk in ("1", "4", "5", "13", "64"):
+            os.environ["DRYV_RECON_CHUNK_FRAMES"] = chunk
+            po[...] = 0
+            recon_ctx.submit_host(fp, frames, pm, pc, po)
+            recon_ctx.sync()
+            assert np.array_equal(po, want), (chunk, first_mismatch(po, want, 23, 11))
+            out = np.zeros_like(want)                     # pageable buffers
+            recon_ctx.submit_host(fp, frames, mbs, co, out)
+            recon_ctx.sync()
+            assert np.array_equal(out, want), chunk
+        # a batch with blocks beyond int32 (wide re-run) and an 8x8 stream (row kernel) through the same path
+        os.environ["DRYV_RECON_CHUNK_FRAMES"] = "3"
+        big = np.clip(co.astype(np.int64) * 6000, -32768, 32767).astype(np.int16)
+        mb51 = mbs.copy()
+        mb51["qp"] = 51
+        st, want_big = oracle.reconstruct(fp, frames, mb51, big)
+        out = np.zeros_like(want)
+        recon_ctx.submit_host(fp, frames, mb51, big, out)
+        recon_ctx.sync()
+        assert st == 0 and np.array_equal(out, want_big)
+        fp8 = abi.make_frame_params(9, 6, transform_8x8=True)
+        m8, c8 = synth.generate(fp8, synth.config(i4x4=0.3, i8x8=0.4), 78, 0, 7)
+        st, want8 = oracle.reconstruct(fp8, 7, m8, c8)
+        out8 = np.zeros_like(want8)
+        recon_ctx.submit_host(fp8, 7, m8, c8, out8)
+        recon_ctx.sync()
+        assert st == 0 and np.array_equal(out8, want8)
+    finally:
+        os.environ.pop("DRYV_RECON_CHUNK_FRAMES", None)
+        for a in (pm, pc, po):
+            recon_ctx.free_host(a)
