@@ -1,7 +1,11 @@
 """The band kernel's source (dryv_amd/csrc/band_kernel.h), compiled for the CPU lane emulator of tests/emu, against
 the oracle. Runs without a GPU: it checks the kernel's index / schedule / arithmetic logic (every lane's program,
-cross-lane operations, LDS layout, band hand-off order); the GPU parity tests (`-m gpu`) remain the proof for the
-machine code. Bit-exact bar. Reference parity itself stays unpinned (see oracle/dryv_oracle.c header)."""
+cross-lane operations, LDS layout, the FRONT/BACK record protocol, band hand-off order with several teams running
+concurrently); the GPU parity tests (`-m gpu`) remain the proof for the machine code. Bit-exact bar. Reference parity
+itself stays unpinned (see oracle/dryv_oracle.c header).
+
+The band kernel serves streams without the 8x8 transform (the library sends the others to the row kernel), so every
+case here is generated with transform_8x8_mode_flag = 0."""
 import os
 import sys
 
@@ -16,9 +20,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import emu  # noqa: E402
 
 
-def check(fp, frames, mbs, co, expect_status=0):
+def check(fp, frames, mbs, co, expect_status=0, teams=1, first=0, order=1):
     st, want = oracle.reconstruct(fp, frames, mbs, co)
-    st2, got = emu.reconstruct(fp, frames, mbs, co)
+    st2, got = emu.reconstruct(fp, frames, mbs, co, teams, first, order)
     assert (st != 0) == (expect_status != 0)
     assert (st2 != 0) == (expect_status != 0)
     W, H = fp.pic_width_in_mbs, fp.pic_height_in_mbs
@@ -49,9 +53,22 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_emulated_band_kernel_matches_oracle(case):
     name, W, H, frames, skw, fkw = case
+    skw, fkw = dict(skw, i8x8=0.0), dict(fkw, transform_8x8=False)
     fp = abi.make_frame_params(W, H, **fkw)
     mbs, co = synth.generate(fp, synth.config(**skw), 100 + CASES.index(case), 0, frames)
     check(fp, frames, mbs, co)
+
+
+@pytest.mark.parametrize("geo", [(7, 5, 3, 6, 0, 1), (7, 5, 3, 6, 5, -1), (7, 5, 1, 2, 1, 1), (5, 13, 2, 8, 7, -1),
+                                 (5, 13, 2, 3, 0, 1), (9, 9, 2, 5, 9, -1)])
+def test_emulated_teams_run_concurrently(geo):
+    """Several teams claim bands at once and are scheduled round-robin in either order (a wave runs until it polls in
+    vain): bands below wait for bands above, BACK waits for FRONT's record and FRONT for BACK's buffer. A deadlock in
+    any of these protocols stops the emulator with "nothing makes progress"."""
+    W, H, frames, teams, first, order = geo
+    fp = abi.make_frame_params(W, H)
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0), 100, 0, frames)
+    check(fp, frames, mbs, co, teams=teams, first=first, order=order)
 
 
 def test_emulated_fuzz():
@@ -59,18 +76,18 @@ def test_emulated_fuzz():
     for k in range(16):
         W, H, frames = int(rng.integers(1, 14)), int(rng.integers(1, 11)), int(rng.integers(1, 3))
         i4 = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
-        i8 = min(float(rng.choice([0.0, 0.3])), 1.0 - i4)
+        i8 = 0.0
         lo = int(rng.integers(0, 40))
         flat = rng.random() < 0.5
-        fkw = dict(transform_8x8=i8 > 0, cqo_cb=int(rng.integers(-12, 13)), cqo_cr=int(rng.integers(-12, 13)))
+        fkw = dict(cqo_cb=int(rng.integers(-12, 13)), cqo_cr=int(rng.integers(-12, 13)))
         if not flat:
-            fkw.update(scaling4x4=rng.integers(4, 48, size=(6, 16)), scaling8x8=rng.integers(4, 48, size=(6, 64)))
+            fkw.update(scaling4x4=rng.integers(4, 48, size=(6, 16)))
         skw = dict(i4x4=i4, i8x8=i8, qp=(lo, int(rng.integers(lo, 52))), coded=float(rng.choice([0.2, 0.6, 1.0])),
                    max_level=int(rng.choice([15, 300, 2047])) if flat else 200,
                    legal_modes_only=bool(rng.random() < 0.7), prev_flag=float(rng.choice([0.1, 0.5, 0.9])))
         fp = abi.make_frame_params(W, H, **fkw)
         mbs, co = synth.generate(fp, synth.config(**skw), 2000 + k, k, frames)
-        check(fp, frames, mbs, co)
+        check(fp, frames, mbs, co, teams=int(rng.integers(1, 4)))
 
 
 @pytest.mark.parametrize("qp_range", [(0, 24), (25, 40), (41, 51)])
@@ -79,11 +96,9 @@ def test_emulated_full_int16_range_every_qp(qp_range):
     Blocks whose coefficients exceed the per-qp int32-exactness bound take the kernel's 64-bit pass."""
     rng = np.random.default_rng(9 + qp_range[0])
     s4 = rng.integers(1, 256, size=(6, 16))
-    s8 = rng.integers(1, 256, size=(6, 64))
-    for lists in (dict(), dict(scaling4x4=s4, scaling8x8=s8)):
-        fp = abi.make_frame_params(6, 5, transform_8x8=True, **lists)
-        mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3, coded=1.0, p0=0.9, decay4=0.97, decay8=0.99,
-                                                  qp=qp_range), 61, 0, 2)
+    for lists in (dict(), dict(scaling4x4=s4)):
+        fp = abi.make_frame_params(6, 5, **lists)
+        mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0, coded=1.0, p0=0.9, decay4=0.97, qp=qp_range), 61, 0, 2)
         scale = rng.choice([1, 40, 700, 6000], size=(co.shape[0], 1))
         co = np.clip(co.astype(np.int64) * scale, -32768, 32767).astype(np.int16)
         check(fp, 2, mbs, co)
