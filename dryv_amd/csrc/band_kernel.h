@@ -5,23 +5,25 @@
 //     row g of the band. The rows advance in lockstep as a 2:1 diagonal: at step s row g works on macroblock
 //     x = s - 2g, so neighbours A, B, C, D of every macroblock (slice/mod.rs:576-613) were finished by the same wave
 //     one or two steps earlier -- no synchronisation between the rows of a band at all.
-//   * A band is worked on by two waves of one workgroup that run on different SIMDs:
-//       FRONT  record decode, all residuals (luma residuals go to a double-buffered LDS area), Intra4x4/8x8 mode
-//              derivation, and ALL of chroma (prediction, staging, stores, hand-off) -- nothing in it depends on a
-//              luma pixel;
-//       BACK   luma prediction (Intra16x16, the Intra4x4 block wavefront), luma staging, stores, hand-off.
-//     The only coupling is the per-step record FRONT leaves in LDS (residuals, table rows, macroblock kinds) and two
-//     LDS words per buffer (ready / free). A lone wave issues about one instruction every 4-5 cycles whatever its
-//     kind, so a step's latency is its instruction count; the split halves it, and with it the frame's critical
+//   * A band is worked on by a team of three waves of one workgroup that run on different SIMDs:
+//       FRONT   record decode, luma residuals (into a double-buffered LDS area), Intra4x4/8x8 mode derivation, and
+//               the fetch of the band above's bottom luma lines for BACK;
+//       BACK    luma prediction (Intra16x16, the Intra4x4 block wavefront), luma staging, stores: the only wave on
+//               the frame's critical path, and it never touches global memory except to store;
+//       CHROMA  all of chroma (residuals, prediction, staging, stores, hand-off): nothing in it depends on a luma
+//               pixel or on the other two waves; it only takes the team's task numbers from FRONT.
+//     FRONT -> BACK coupling is the per-step record in LDS (residuals, table rows, macroblock kinds) and two LDS words
+//     per buffer (ready / free). A lone wave issues about one instruction every 4-5 cycles whatever its kind, so a
+//     step's latency is the instruction count of the slowest wave; the split cuts it, and with it the frame's critical
 //     path (a frame is a 2:1 wavefront of 120 + 2 x 67 macroblock steps that no amount of parallel frames shortens).
 //   * Bands come off one queue in band-major order (band 0 of every frame, band 1 of every frame, ...): a band's
 //     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running or done, so
 //     there is no deadlock at any residency.
 //   * Between bands the hand-off goes through L2 (MI355X_MICROARCH.md "valid forms", sc1 stores + drained flag,
-//     sc1 loads), separately for luma (BACK: bottom pixel line) and chroma (FRONT: bottom lines + bottom-row
-//     modes): the band's last row stores them write-through and, a good part of a step later -- when s_waitcnt
-//     vmcnt(0) has shown those stores complete -- publishes its progress word. The band below reads that word one
-//     step ahead and fetches one macroblock's lines per step.
+//     sc1 loads), separately for luma (BACK stores, the FRONT of the band below fetches), chroma (CHROMA) and the
+//     bottom-row modes (FRONT): the band's last row stores them write-through and, a good part of a step later --
+//     when s_waitcnt vmcnt(0) has shown those stores complete -- publishes its progress word. The band below reads
+//     that word one step ahead and fetches one macroblock's lines per step.
 //
 // Inside a step (4 macroblocks)
 //   * residual: ONE LANE PER 4x4 BLOCK. The lane loads its block's 16 coefficients (32 contiguous bytes of the
@@ -64,24 +66,34 @@ constexpr int TILE_BYTES = 704;  // 17 rows x 40 + 8 (row y = -1 of slot 1 reach
 constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [blkIdx][y][x]
 constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       Intra4x4 table row per chain step and block half
 constexpr int S_INFO = 4288;     // u32 [2][8]              kinds of the 4 macroblocks, Intra16x16 modes, task, step
-constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2]   (global step count + 1 of the record in / consumed from the buffer)
-// BACK
+constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2] (global step count + 1 of the record in / consumed from the
+                                 //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks)
+constexpr int F_READY = 0, F_FREE = 8, F_TASKS = 16, F_HEAD = 32, F_TAILC = 36;
+// BACK (+ FRONT writes row 0 of the luma ring: lines fetched from the band above)
 constexpr int S_TILE = 4416;     // u8  [4][TILE_BYTES]  luma: row j = y + 1, column 8 + 16 * (x & 1) + xr
-constexpr int S_RINGY = S_TILE + 4 * TILE_BYTES;  // u8 [4][4][16]  bottom luma lines of the row above
-constexpr int S_LEFTY = S_RINGY + 256;            // u8 [4][16]     column 15 of the macroblock to the left
-// FRONT
+constexpr int S_RINGY = S_TILE + 4 * TILE_BYTES;  // bottom luma lines of the row above: row 0 [2][8][16], rows 1..3 [4][16]
+constexpr int S_LEFTY = S_RINGY + 448;            // u8 [4][16]     column 15 of the macroblock to the left
+// CHROMA
 constexpr int S_STC = S_LEFTY + 64;               // u8 [4][2][8][16] chroma staging, two macroblocks wide
-constexpr int S_RINGC = S_STC + 1024;             // [4][4][24]  bottom chroma lines of the row above: Cb[8] Cr[8] modes
-constexpr int RINGC_ROW = 96, RINGC_ENT = 24;
-constexpr int S_LEFTC = S_RINGC + 384;            // u8 [4][2][8]
-constexpr int S_BYTES = 9088;                     // (64-byte multiple)
-static_assert(S_LEFTC + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
+constexpr int S_RINGC = S_STC + 1024;             // [4][4][16]  bottom chroma lines of the row above: Cb[8] Cr[8]
+constexpr int RINGC_ROW = 64, RINGC_ENT = 16;
+constexpr int S_LEFTC = S_RINGC + 256;            // u8 [4][2][8]
+// FRONT
+constexpr int S_RINGM = S_LEFTC + 64;             // u32 [4][4]  bottom-row modes of the row above
+constexpr int S_BYTES = 9152;                     // (64-byte multiple)
+static_assert(S_RINGM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
+// luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
+// two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
+WV int ringy(int ts, int g, int e, int par) {
+  return g == 0 ? ts + S_RINGY + 128 * par + 16 * (e & 7) : ts + S_RINGY + 256 + 64 * (g - 1) + 16 * (e & 3);
+}
 
 #ifndef DRYV_BAND_TEAMS
-#define DRYV_BAND_TEAMS 4   // teams per workgroup (tools/band_variants.sh: 4 x 3 workgroups per CU measured best)
+#define DRYV_BAND_TEAMS 3   // teams per workgroup (tools/band_variants.sh)
 #endif
 constexpr int TEAMS_PER_WG = DRYV_BAND_TEAMS;
-constexpr int WAVES_PER_WG = 2 * TEAMS_PER_WG;
+constexpr int WAVES_PER_TEAM = 3;  // FRONT, BACK, CHROMA
+constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a progress word (about a second) before a band gives up
 constexpr unsigned TASK_END = 0xFFFFFFFFu;
 
@@ -122,7 +134,8 @@ struct Args {
   uint8_t* yuv;
   unsigned* status;
   unsigned* progY;      // [frame][band]: macroblocks of the band's last row whose bottom luma line is visible
-  unsigned* progC;      // [frame][band]: the same for its bottom chroma lines and bottom-row modes
+  unsigned* progC;      // [frame][band]: the same for its bottom chroma lines
+  unsigned* progM;      // [frame][band]: the same for its bottom-row modes
   unsigned* rowModes;   // [mb]: bottom-row Intra4x4/8x8 modes (only rows that end a band are written)
   unsigned* taskCounter;
   unsigned long long* profile;  // DRYV_BAND_PROFILE builds only
@@ -341,18 +354,22 @@ WV BandGeo band_geo(unsigned task, int nF, int W, int H) {
   return G;
 }
 
-// Waits (polling LDS) until the team's flag word at `addr` equals `want`.
+// Waits (polling LDS) until the team's flag word at `addr` equals `want` / has reached it.
 WV void team_wait(int addr, unsigned want) {
   while ((unsigned)wv::rfl((int)wv::lds_u32(addr)) != want) wv::sleep_team();
 }
+WV void team_wait_ge(int addr, unsigned want) {
+  while ((int)((unsigned)wv::rfl((int)wv::lds_u32(addr)) - want) < 0) wv::sleep_team();
+}
 
-// Polls the progress word of the band above until it reaches `need` (bounded: see SPIN_LIMIT).
-WV unsigned poll_progress(const unsigned* prog, unsigned known, unsigned need, unsigned W, unsigned* status, unsigned task,
-                          int s, int lane) {
+// Polls progress words of the band above until they reach `need` (bounded: see SPIN_LIMIT). Lanes 0..31 read pa,
+// lanes 32..63 pb (the same word twice where a wave follows only one).
+WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned known, unsigned need, unsigned W, unsigned* status,
+                          unsigned task, int s, int lane) {
   unsigned spins = 0;
   while (known < need) {
-    const unsigned v = wv::ld_sc1(prog);  // (all lanes, one address: one request)
-    known = (unsigned)wv::rfl((int)v);
+    const unsigned v = wv::ld_sc1(lane < 32 ? pa : pb);  // (all lanes: see the claim in band_front)
+    known = min((unsigned)wv::rfl((int)v), (unsigned)wv::rdlane((int)v, 32));
     if (known < need) {
       wv::sleep_short();
       if (++spins > SPIN_LIMIT) {
@@ -371,7 +388,7 @@ WV unsigned poll_progress(const unsigned* prog, unsigned known, unsigned need, u
 }
 
 // ==================================================================================================================
-// FRONT wave: records, residuals, mode derivation, chroma
+// FRONT wave: records, luma residuals, mode derivation, the band above's luma lines for BACK
 // ==================================================================================================================
 template <bool HAS_I8, bool WIDE>
 WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int ts) {
@@ -385,24 +402,29 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
   const int W = P.W, H = P.H, nF = P.n_frames;
   const int nBands = (H + 3) >> 2;
   const unsigned totalTasks = (unsigned)nF * (unsigned)nBands;
-  const int pitchC = W * 8;
+  const int pitchY = W * 16;
   const size_t frameBytes = (size_t)W * H * 384;
-  const unsigned offCb = (unsigned)W * H * 256u, offCr = offCb + (unsigned)W * H * 64u;
   unsigned gstep = 0;  // steps of this team so far, over all its tasks: buffer = parity, flags carry gstep + 1
 
-  for (;;) {
+  for (unsigned seq = 0;; seq++) {
     // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
     // a single-lane conditional in front of a readfirstlane invites the compiler to thread that condition through the
     // loop, after which the readfirstlane executes under a partial exec mask and returns another lane's value.
     const unsigned tsk = wv::atomic_add_task(A.taskCounter, lane0 == 0 ? 1u : 0u);
     const unsigned task = (unsigned)wv::rfl((int)tsk);
-    if (task >= totalTasks) {
+    const bool last = task >= totalTasks;
+    // CHROMA follows through a ring of four task numbers
+    if (seq >= 4) team_wait_ge(ts + S_FLAGS + F_TAILC, seq - 3);
+    if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_TASKS + 4 * (int)(seq & 3u), last ? TASK_END : task);
+    wv::wave_sync();
+    if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_HEAD, seq + 1);
+    if (last) {
       // tell BACK to stop: an end record in the next buffer
       const int buf = (int)(gstep & 1u);
-      if (gstep >= 2) team_wait(ts + S_FLAGS + 8 + 4 * buf, gstep - 1);
+      if (gstep >= 2) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - 1);
       if (lane0 == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 16, TASK_END);
       wv::wave_sync();
-      if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + 4 * buf, gstep + 1);
+      if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);
       break;
     }
     TRACE(0, task + 1u);
@@ -411,13 +433,14 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     const bool hasAbove = G.hasAbove, hasBelow = G.hasBelow;
     // per-frame bases (wave-uniform); everything below addresses them with 32-bit offsets: a frame's planes, records
     // and coefficients are each < 4 GB (the host API checks)
-    uint8_t* const planeY = A.yuv + (size_t)G.f * frameBytes;
+    const uint8_t* const planeY = A.yuv + (size_t)G.f * frameBytes;
     const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
     const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
     uint8_t* const modesF = (uint8_t*)(A.rowModes + mbFrame);
-    unsigned* const myProg = A.progC + (size_t)G.f * nBands + G.b;
-    const unsigned* const upProg = myProg - 1;
+    unsigned* const myProg = A.progM + (size_t)G.f * nBands + G.b;
+    const unsigned* const upProgM = myProg - 1;
+    const unsigned* const upProgY = A.progY + (size_t)G.f * nBands + G.b - 1;
 
     // ---- software pipeline: a step's record is fetched one step ahead (its first word, which decides the
     // coefficient layout, two steps ahead); its coefficients are fetched right after the previous step's residual
@@ -435,10 +458,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       const int l = wv::opaque(lane0);
       return *(const unsigned*)(mbsF + 16u * mb_index(step, l >> 4));
     };
-    u32x4 cA0, cA1, cB0, cB1;
-    int dcA, dcB;
-    cB0 = cB1 = u32x4{0, 0, 0, 0};
-    dcB = 0;
+    u32x4 cA0, cA1;
+    int dcA;
     auto load_coefs_luma = [&](int step, unsigned d0) {
       const int l = wv::opaque(lane0);
       const int i = l & 15;
@@ -452,28 +473,16 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       cA1 = wv::ld_u128_a2(coefF + (mo + (unsigned)off + 16u));
       dcA = *(const int16_t*)(coefF + (mo + 2u * (unsigned)ZZ4IDX(zby, zbx)));
     };
-    auto load_coefs_chroma = [&](int step) {
-      const int l = wv::opaque(lane0);
-      if (l < 32) {
-        const int cpl = (l >> 2) & 1, cblk = l & 3;
-        const unsigned mo = mb_index(step, (l >> 3) & 3) * 768u;
-        const unsigned offc = 2u * (unsigned)(259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
-        cB0 = wv::ld_u128_a2(coefF + (mo + offc));
-        cB1 = wv::ld_u128_a2(coefF + (mo + offc + 16u));
-        dcB = *(const int16_t*)(coefF + (mo + 2u * (unsigned)(256 + 64 * cpl + cblk)));
-      }
-    };
     u32x4 dN1 = load_desc(0);
     unsigned kN2 = load_kind(1);
     load_coefs_luma(0, dN1.x);
-    load_coefs_chroma(0);
 
     PH(0);  // claim, prologue loads
     int Mprev = 2;           // derived modes of the macroblock to the left on the raster block grid
-    unsigned upKnown = 0;    // what this wave knows of the band above's (chroma) progress
-    unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
+    unsigned upKnown = 0;    // what this wave knows of the band above's progress: min(luma lines, modes)
+    unsigned flagV = 0;      // the band above's progress words, fetched during the previous step
     bool flagPend = false;
-    bool linePend = false;   // bottom lines of the band's last row were stored in the previous step, not yet published
+    bool linePend = false;   // bottom-row modes of the band's last row were stored in the previous step, not yet published
 
     for (int s = 0; s < nSteps; s++, gstep++) {
       TRACE(1, s + 1);
@@ -485,16 +494,11 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       const int g = lane >> 4, i = lane & 15;
       const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
       const int rbx = i & 3, rby = i >> 2;                                              // mode grid: raster
-      const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;           // chroma lane-per-block (lanes 0..31)
-      const int ccx = cblk & 1, ccy = cblk >> 1;
-      const bool chromaLane = lane < 32;
-      const int ringC = ts + S_RINGC + RINGC_ROW * g;   // chroma lines + modes of the row above row g (luma lane roles)
-      const int r = r0 + g, rC = r0 + gc;
-      const bool rowOk = g < nR, rowOkC = gc < nR;
-      const bool mbB = r > 0, mbBC = rC > 0;
-      const int x = s - 2 * g, xC = s - 2 * gc;
-      const bool valid = rowOk && x >= 0 && x < W, validC = rowOkC && xC >= 0 && xC < W;
-      const int slot = s & 1;  // (x & 1 for every row)
+      const int r = r0 + g;
+      const bool rowOk = g < nR;
+      const bool mbB = r > 0;
+      const int x = s - 2 * g;
+      const bool valid = rowOk && x >= 0 && x < W;
       const bool needUp = hasAbove && s < W;
       unsigned lineV = 0;
 
@@ -511,10 +515,6 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         qp = 0;
       }
       const bool mbA = x > 0, mbC = mbB && (x + 1 < W);
-      // the same for the chroma organisation (row gc): record word 0 from lane 16*gc
-      const unsigned dC = (unsigned)wv::bperm((int)((unsigned)kind | (dCur.x & 0x00ffff00u) | ((unsigned)qp << 24)), 16 * gc);
-      const int kindC = (int)(dC & 0xffu), cmode = (int)((dC >> 16) & 0xffu), qpC = (int)(dC >> 24);
-      const bool mbAC = xC > 0;
 
       PH(1);  // record decode
       // ================= residuals ================================================================================
@@ -550,36 +550,33 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       }
       PH(2);  // luma residuals
       // ---- hand-off traffic, placed here so that nothing in front of the residuals waits for it.
-      // Publish: the previous step ended with the write-through stores of its last-row macroblock's bottom chroma lines
-      // and modes (and the staged row segments). They have had a residual pass to drain; once vmcnt says that everything
-      // this wave has issued is done (loads and stores count together, in order) the macroblock is published.
+      // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom-row modes.
+      // It has had a residual pass to drain; once vmcnt says that everything this wave has issued is done (loads and
+      // stores count together, in order) the macroblock is published.
       if (linePend) {
         wv::wait_vm(0);
         const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
         if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
         linePend = false;
       }
+      // lanes 0..4: macroblock s+1 of the band above's last row (0..3 bottom luma line, 4 modes); lanes 16..20:
+      // macroblock 0 at step 0
+      const int li = lane & 15;
+      const int mbx = lane < 16 ? s + 1 : 0;
+      const bool fetchLane = needUp && li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
       if (needUp) {
-        // the band above must have finished macroblock s+1 before its lines are fetched. Its progress word is read
-        // one step ahead (flagV), so this normally costs nothing; otherwise poll.
-        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
+        // the band above must have finished macroblock s+1 (luma: BACK's neighbour C; modes) before they are fetched.
+        // Its progress words are read one step ahead (flagV), so this normally costs nothing; otherwise poll.
+        if (flagPend) upKnown = max(upKnown, min((unsigned)wv::rfl((int)flagV), (unsigned)wv::rdlane((int)flagV, 32)));
         flagPend = false;
-        upKnown = poll_progress(upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
+        upKnown = poll_progress(upProgY, upProgM, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
         wv::compiler_fence();
-        // lanes 0..4: macroblock s+1 (0..1 Cb, 2..3 Cr, 4 modes); lanes 16..20: macroblock 0 at step 0
-        const int li = lane & 15;
-        const int mbx = lane < 16 ? s + 1 : 0;
-        const bool act = li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-        if (act) {
-          if (li < 4) {
-            const unsigned off = (li < 2 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
-            lineV = wv::ld_sc1((const unsigned*)(planeY + off));
-          } else {
-            lineV = wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mbx)));
-          }
+        if (fetchLane) {
+          if (li < 4) lineV = wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mbx + 4 * li)));
+          else lineV = wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mbx)));
         }
         if (upKnown < (unsigned)W) {
-          flagV = wv::ld_sc1(upProg);
+          flagV = wv::ld_sc1(lane < 32 ? upProgY : upProgM);
           flagPend = true;
         }
       }
@@ -588,21 +585,21 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
 
       // ---- the step's record for BACK: residuals [blkIdx][y][x], table rows, kinds. The buffer is free once BACK has
       // finished the step two back.
-      if (gstep >= 2) team_wait(ts + S_FLAGS + 8 + 4 * buf, gstep - 1);
+      if (gstep >= 2) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - 1);
       wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
       wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
       if (i == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 4 * g, (unsigned)kind | ((unsigned)i16mode << 8));
       if (lane == 0) {
         wv::lds_st32(ts + S_INFO + 32 * buf + 16, task);
         wv::lds_st32(ts + S_INFO + 32 * buf + 20, (unsigned)s);
+        wv::lds_st32(ts + S_INFO + 32 * buf + 24, seq & 1u);
       }
-      // chroma lines + modes of the band above: this step's fetched macroblock goes into row 0's ring
-      if (needUp) {
-        const int li = lane & 15;
-        const int mbx = lane < 16 ? s + 1 : 0;
-        const bool act = li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-        if (act) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * li, lineV);
-      }
+      // what was fetched from the band above goes into row 0's rings (BACK's luma ring, the modes ring): at step 0 now
+      // (macroblock 0 is this step's neighbour B), otherwise behind the mode derivation, which hides the fetch
+      auto store_fetched = [&]() {
+        if (fetchLane) wv::lds_st32(li < 4 ? ringy(ts, 0, mbx, (int)(seq & 1u)) + 4 * li : ts + S_RINGM + 4 * (mbx & 3), lineV);
+      };
+      if (s == 0) store_fetched();
       wv::wave_sync();
 
       // ================= Intra4x4 prediction modes (8.3.1.1, pred4x4.rs:363-427) ==================================
@@ -614,7 +611,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         const int mzb = zidx(rbx, rby);
         const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
         const bool prev = ((prevFlags >> mzb) & 1u) != 0;
-        const unsigned upM = mbB ? wv::lds_u32(ringC + RINGC_ENT * (x & 3) + 16) : 0x02020202u;
+        const unsigned upM = mbB ? wv::lds_u32(ts + S_RINGM + 16 * g + 4 * (x & 3)) : 0x02020202u;
         const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
         const int Lb = wv::dpp<DPP_ROW_SHL(3)>(Mprev, Mprev);
         const bool unav = (rbx == 0 && !mbA) || (rby == 0 && !mbB);
@@ -646,9 +643,162 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         }
       }
 
+      if (s != 0) store_fetched();
       wv::wave_sync();
-      if (lane == 0) wv::lds_st32(ts + S_FLAGS + 4 * buf, gstep + 1);  // the record is complete
+      if (lane == 0) wv::lds_st32(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);  // the record is complete
       PH(4);  // record for BACK, modes
+
+      // the record of step s+1, the first record word of step s+2
+      dN1 = load_desc(s + 1);
+      kN2 = load_kind(s + 2);
+      // bottom-row modes for the row below (ring) or the band below (write-through)
+      {
+        unsigned m4 = (unsigned)Mcur << (8 * (i & 3));
+        m4 |= (unsigned)xor1((int)m4);
+        m4 |= (unsigned)xor2((int)m4);  // lanes 12..15 of the row group: the four bottom-row modes
+        if (valid && i == 12 && g < 3 && g < gl) wv::lds_st32(ts + S_RINGM + 16 * (g + 1) + 4 * (x & 3), m4);
+        if (hasBelow && wv::any(valid && g == gl)) {
+          if (valid && g == gl && i == 12) wv::st_sc1((unsigned*)(modesF + 4u * (unsigned)(r * W + x)), m4);
+          linePend = true;
+        }
+      }
+      Mprev = valid ? Mcur : 2;
+      wv::wave_sync();
+      PH(5);  // prefetch, modes hand-off
+    }
+    // the band's modes are complete once the last store has been written through
+    if (hasBelow) {
+      wv::wait_vm(0);
+      if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
+    }
+    TRACE(6, task + 1u);
+  }
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  TRACE(7, 0xD0E);
+#endif
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  if (lane0 == 0 && A.profile)
+    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
+#endif
+}
+
+// ==================================================================================================================
+// CHROMA wave: chroma residuals, prediction, write-out and hand-off, following the tasks FRONT claims
+// ==================================================================================================================
+template <bool HAS_I8, bool WIDE>
+WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const int ts) {
+  const int lane0 = wv::lane_id();
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  unsigned long long phAcc[BAND_NPH];
+  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
+  unsigned long long phT = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+  const int W = P.W, H = P.H, nF = P.n_frames;
+  const int nBands = (H + 3) >> 2;
+  const int pitchC = W * 8;
+  const size_t frameBytes = (size_t)W * H * 384;
+  const unsigned offCb = (unsigned)W * H * 256u, offCr = offCb + (unsigned)W * H * 64u;
+
+  for (unsigned seq = 0;; seq++) {
+    team_wait_ge(ts + S_FLAGS + F_HEAD, seq + 1);
+    const unsigned task = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_FLAGS + F_TASKS + 4 * (int)(seq & 3u)));
+    wv::wave_sync();
+    if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_TAILC, seq + 1);
+    if (task == TASK_END) break;
+    const BandGeo G = band_geo(task, nF, W, H);
+    const int r0 = G.r0, nR = G.nR, gl = G.gl, nSteps = G.nSteps;
+    const bool hasAbove = G.hasAbove, hasBelow = G.hasBelow;
+    uint8_t* const planeY = A.yuv + (size_t)G.f * frameBytes;
+    const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
+    const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
+    const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
+    unsigned* const myProg = A.progC + (size_t)G.f * nBands + G.b;
+    const unsigned* const upProg = myProg - 1;
+
+    // software pipeline as in FRONT: first record word and coefficients one step ahead
+    auto mb_index = [&](int step, int g) -> unsigned {  // within the frame
+      const int x = min(max(step - 2 * g, 0), W - 1);
+      return (unsigned)(min(r0 + g, H - 1) * W + x);
+    };
+    auto load_kind = [&](int step) -> unsigned {
+      const int l = wv::opaque(lane0);
+      return *(const unsigned*)(mbsF + 16u * mb_index(step, (l >> 3) & 3));
+    };
+    u32x4 cB0, cB1;
+    int dcB;
+    cB0 = cB1 = u32x4{0, 0, 0, 0};
+    dcB = 0;
+    auto load_coefs_chroma = [&](int step) {
+      const int l = wv::opaque(lane0);
+      if (l < 32) {
+        const int cpl = (l >> 2) & 1, cblk = l & 3;
+        const unsigned mo = mb_index(step, (l >> 3) & 3) * 768u;
+        const unsigned offc = 2u * (unsigned)(259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
+        cB0 = wv::ld_u128_a2(coefF + (mo + offc));
+        cB1 = wv::ld_u128_a2(coefF + (mo + offc + 16u));
+        dcB = *(const int16_t*)(coefF + (mo + 2u * (unsigned)(256 + 64 * cpl + cblk)));
+      }
+    };
+    unsigned kN1 = load_kind(0);
+    load_coefs_chroma(0);
+    PH(0);  // task, prologue loads
+    unsigned upKnown = 0;    // what this wave knows of the band above's chroma progress
+    unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
+    bool flagPend = false;
+    bool linePend = false;   // bottom lines of the band's last row were stored in the previous step, not yet published
+
+    for (int s = 0; s < nSteps; s++) {
+      const unsigned dC = kN1;
+      const int lane = wv::opaque(lane0);
+      const int g = lane >> 4, i = lane & 15;                                            // write-out organisation: row g
+      const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;           // lane-per-block (lanes 0..31)
+      const int ccx = cblk & 1, ccy = cblk >> 1;
+      const bool chromaLane = lane < 32;
+      const int r = r0 + g, rC = r0 + gc;
+      const bool mbBC = rC > 0;
+      const int x = s - 2 * g, xC = s - 2 * gc;
+      const bool valid = g < nR && x >= 0 && x < W, validC = gc < nR && xC >= 0 && xC < W;
+      const bool mbAC = xC > 0;
+      const int slot = s & 1;  // (x & 1 for every row)
+      const bool needUp = hasAbove && s < W;
+      unsigned lineV = 0;
+      // the record checks FRONT makes (it also reports them): an unsupported record reconstructs as zero
+      int kindC = (int)(dC & 0xffu), qpC = (int)(dC >> 24);
+      const int cmode = (int)((dC >> 16) & 0xffu);
+      if (kindC > 2 || (!HAS_I8 && kindC == 1) || qpC > 51 || ((dC >> 8) & 0xffu) > 3u || cmode > 3) {
+        kindC = 3;
+        qpC = 0;
+      }
+
+      // ---- hand-off traffic. Publish: the previous step ended with the write-through stores of its last-row
+      // macroblock's bottom chroma lines (and the staged row segments); once vmcnt says that everything this wave has
+      // issued is done the macroblock is published.
+      if (linePend) {
+        wv::wait_vm(0);
+        const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
+        if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
+        linePend = false;
+      }
+      // lanes 0..3: bottom lines of macroblock s+1 of the band above (0..1 Cb, 2..3 Cr); lanes 16..19: macroblock 0 at step 0
+      const int li = lane & 15;
+      const int mbx = lane < 16 ? s + 1 : 0;
+      const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+      if (needUp) {
+        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
+        flagPend = false;
+        upKnown = poll_progress(upProg, upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
+        wv::compiler_fence();
+        if (fetchLane) {
+          const unsigned off = (li < 2 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
+          lineV = wv::ld_sc1((const unsigned*)(planeY + off));
+        }
+        if (upKnown < (unsigned)W) {
+          flagV = wv::ld_sc1(upProg);
+          flagPend = true;
+        }
+      }
+      PH(1);  // hand-off traffic
 
       // ================= chroma residuals ==========================================================================
       unsigned rB[8];
@@ -671,11 +821,11 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         }
       }
       load_coefs_chroma(s + 1);
-      // ... and the record of step s+1, the first record word of step s+2
-      dN1 = load_desc(s + 1);
-      kN2 = load_kind(s + 2);
+      kN1 = load_kind(s + 1);
+      if (fetchLane) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * li, lineV);
+      wv::wave_sync();
+      PH(2);  // chroma residuals, prefetch
 
-      PH(5);  // chroma residuals, prefetch
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (row gc, plane, block) ===================
       {
         const int ringP = ts + S_RINGC + RINGC_ROW * gc + 8 * cpl;
@@ -755,46 +905,26 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       }
 
       wv::wave_sync();
-
-      wv::wave_sync();
-      PH(6);  // chroma prediction
+      PH(3);  // chroma prediction
 
       // ================= chroma write-out =========================================================================
-      // The prefetched record and coefficients are "used" here, in front of this step's stores: the compiler then
+      // The prefetched record word and coefficients are "used" here, in front of this step's stores: the compiler then
       // waits for those loads now (they were issued thousands of cycles ago) instead of at the top of the next step,
       // where its vmcnt(0) would also wait for the stores below -- and a write-through store takes thousands of cycles
       // to be acknowledged when the chip is busy. (Measured alternative, not kept: a constant number of stores per step,
       // padded with stores to a dump area, so that the compiler could count them: its waits stayed vmcnt(0) across the
       // loop back-edge and the batch took longer.)
-      dN1.x = (unsigned)wv::opaque((int)dN1.x); dN1.y = (unsigned)wv::opaque((int)dN1.y);
-      dN1.z = (unsigned)wv::opaque((int)dN1.z); dN1.w = (unsigned)wv::opaque((int)dN1.w);
-      kN2 = (unsigned)wv::opaque((int)kN2);
-      cA0.x = (unsigned)wv::opaque((int)cA0.x); cA1.x = (unsigned)wv::opaque((int)cA1.x); dcA = wv::opaque(dcA);
+      kN1 = (unsigned)wv::opaque((int)kN1);
       cB0.x = (unsigned)wv::opaque((int)cB0.x); cB1.x = (unsigned)wv::opaque((int)cB1.x); dcB = wv::opaque(dcB);
-      // bottom chroma lines and bottom-row modes for the row below (ring) or the band below (write-through)
-      const unsigned m4 = [&]() {
-        unsigned v = (unsigned)Mcur << (8 * (i & 3));
-        v |= (unsigned)xor1((int)v);
-        v |= (unsigned)xor2((int)v);
-        return v;  // lanes 12..15 of the row group: the four bottom-row modes
-      }();
+      // bottom chroma lines for the row below (ring) or the band below (write-through): lanes 0..1 of row g Cb, 2..3 Cr
       {
-        // lanes of row g: 0..1 Cb dwords, 2..3 Cr (bottom line), 12: modes
-        const int stc = ts + S_STC + 256 * g;
         unsigned v = 0;
-        if (i < 4) v = wv::lds_u32(stc + 128 * (i >> 1) + 16 * 7 + 8 * slot + 4 * (i & 1));
-        else if (i == 12) v = m4;
-        const bool lineLane = i < 4 || i == 12;
-        const int fo = i < 4 ? 4 * i : 16;
-        if (valid && lineLane && g < 3 && g < gl) wv::lds_st32(ts + S_RINGC + RINGC_ROW * (g + 1) + RINGC_ENT * (x & 3) + fo, v);
+        if (i < 4) v = wv::lds_u32(ts + S_STC + 256 * g + 128 * (i >> 1) + 16 * 7 + 8 * slot + 4 * (i & 1));
+        if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ts + S_RINGC + RINGC_ROW * (g + 1) + RINGC_ENT * (x & 3) + 4 * i, v);
         if (hasBelow && wv::any(valid && g == gl)) {  // the band's last row: written through for the band below
-          if (valid && g == gl && lineLane) {
-            if (i < 4) {
-              const unsigned off = (i < 2 ? offCb : offCr) + (unsigned)((8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
-              wv::st_sc1((unsigned*)(planeY + off), v);
-            } else {
-              wv::st_sc1((unsigned*)(modesF + 4u * (unsigned)(r * W + x)), v);
-            }
+          if (valid && g == gl && i < 4) {
+            const unsigned off = (i < 2 ? offCb : offCr) + (unsigned)((8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
+            wv::st_sc1((unsigned*)(planeY + off), v);
           }
           linePend = true;
         }
@@ -805,7 +935,6 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         const unsigned c = wv::lds_u8(ts + S_STC + 256 * g + 128 * pl + 16 * yy + 8 * slot + 7);
         wv::lds_st8(ts + S_LEFTC + 16 * g + 8 * pl + yy, c);
       }
-      Mprev = valid ? Mcur : 2;
       wv::wave_sync();
       // flush the staged rows: every second macroblock, or at the end of a row: 16 contiguous bytes per pixel row.
       // The bottom lines of a band that has a band below were already written through.
@@ -821,17 +950,15 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         }
       }
       wv::wave_sync();
-      PH(7);  // chroma lines, copies, flush
+      PH(4);  // chroma lines, copies, flush
     }
     // the band's chroma is complete once its last stores have been written through
     if (hasBelow) {
       wv::wait_vm(0);
       if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
     }
-    TRACE(6, task + 1u);
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  TRACE(7, 0xD0E);
   if (lane0 == 0 && A.profile)
     for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
 #endif
@@ -857,26 +984,24 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
   BandGeo G = band_geo(0u, nF, W, H);
   uint8_t* planeY = A.yuv;
   unsigned* myProg = A.progY;
-  unsigned upKnown = 0, flagV = 0;
-  bool flagPend = false, linePend = false;
+  bool linePend = false;
+  int par = 0;  // task parity (row 0's luma ring)
 
   for (unsigned gstep = 0;; gstep++) {
     const int buf = (int)(gstep & 1u);
-    team_wait(ts + S_FLAGS + 4 * buf, gstep + 1);
+    team_wait(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);
     const unsigned task = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 16));
     if (task == TASK_END) break;
     const int s = wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 20));
     if (s == 0) {
       G = band_geo(task, nF, W, H);
+      par = wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 24));
       planeY = A.yuv + (size_t)G.f * frameBytes;
       myProg = A.progY + (size_t)G.f * nBands + G.b;
-      upKnown = 0;
-      flagPend = false;
       linePend = false;
     }
     const int r0 = G.r0, nR = G.nR, gl = G.gl;
-    const bool hasAbove = G.hasAbove, hasBelow = G.hasBelow;
-    const unsigned* const upProg = myProg - 1;
+    const bool hasBelow = G.hasBelow;
     const int resBuf = ts + S_RES + 2048 * buf;
 
     const int lane = wv::opaque(lane0);
@@ -884,7 +1009,6 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
     const int ch = (i >> 3) & 1, cp = i & 7;                                          // Intra4x4 chain: block half, pixel pair
     const int tile = ts + S_TILE + TILE_BYTES * g;
-    const int ringMine = ts + S_RINGY + 64 * g;         // luma lines of the row above row g
     const int r = r0 + g;
     const bool rowOk = g < nR;
     const bool mbB = r > 0;
@@ -892,41 +1016,20 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     const bool valid = rowOk && x >= 0 && x < W;
     const bool mbA = x > 0;
     const int slot = s & 1;  // (x & 1 for every row)
-    const bool needUp = hasAbove && s < W;
     const unsigned info = wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g);
     const int kind = (int)(info & 0xffu), i16mode = (int)((info >> 8) & 0xffu);
-    unsigned lineV = 0;
-    PH(8);  // wait for the record
+    PH(0);  // wait for the record
 
-    // ---- band above: its last row must have finished macroblock s+1 (neighbour C of row 0); fetch that macroblock's
-    // bottom luma line; the progress word for the next step is fetched too
-    if (needUp) {
-      if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
-      flagPend = false;
-      upKnown = poll_progress(upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
-      wv::compiler_fence();
-      // lanes 0..3: macroblock s+1; lanes 16..19: macroblock 0 at step 0
-      const int li = lane & 15;
-      const int mbx = lane < 16 ? s + 1 : 0;
-      const bool act = li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-      if (act) lineV = wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mbx + 4 * li)));
-      if (upKnown < (unsigned)W) {
-        flagV = wv::ld_sc1(upProg);
-        flagPend = true;
-      }
-      // (step 0 of a band below another: macroblock 0's line has only just been requested)
-      if (s == 0 && li < 4 && lane >= 16 && lane < 32) wv::lds_st32(ts + S_RINGY + 4 * li, lineV);
-    }
-    wv::wave_sync();
+    // (the bottom luma lines of the band above are in row 0's ring: FRONT fetched them)
     // top border of the luma tile, first part: corner dword of x-1, 16 bytes of x
     if (i < 5) {
       const int e = i == 0 ? x - 1 : x;
       const int so = i == 0 ? 12 : 4 * (i - 1);
-      const unsigned v = wv::lds_u32(ringMine + 16 * (e & 3) + so);
+      const unsigned v = wv::lds_u32(ringy(ts, g, e, par) + so);
       wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
     }
     wv::wave_sync();
-    PH(9);  // hand-off traffic, top border
+    PH(1);  // top border
 
       // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
       if (wv::any(valid && kind >= 2)) {
@@ -1003,29 +1106,23 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       }
 
       wv::wave_sync();
-      PH(10);  // Intra16x16
+      PH(2);  // Intra16x16
 
-      // ================= top-right neighbour: the fetched macroblock s+1 goes into row 0's ring, then 8 bytes of x+1
-      if (needUp) {
-        const int li = lane & 15;
-        if (li < 4 && lane < 16 && s + 1 < W) wv::lds_st32(ts + S_RINGY + 16 * ((s + 1) & 3) + 4 * li, lineV);
-        wv::wave_sync();
-      }
+      // ================= top-right neighbour: 8 bytes of x+1
       if (i == 5 || i == 6) {
-        const unsigned v = wv::lds_u32(ringMine + 16 * ((x + 1) & 3) + 4 * (i - 5));
+        const unsigned v = wv::lds_u32(ringy(ts, g, x + 1, par) + 4 * (i - 5));
         wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
       }
       wv::wave_sync();
       // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom line (and the
-      // staged row segments); this step's only load so far has just been consumed. Once vmcnt says that everything this
-      // wave has issued is done the macroblock is published.
+      // staged row segments). Once vmcnt says that everything this wave has issued is done the macroblock is published.
       if (linePend) {
         wv::wait_vm(0);
         const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
         if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
         linePend = false;
       }
-      PH(11);  // top-right copy, publish
+      PH(3);  // top-right copy, publish
       const bool anyI4 = wv::any(valid && kind == 0);
 
       // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================
@@ -1083,15 +1180,15 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 
       // the record has been consumed
       wv::wave_sync();
-      if (lane == 0) wv::lds_st32(ts + S_FLAGS + 8 + 4 * buf, gstep + 1);
-      PH(12);  // Intra4x4 chain
+      if (lane == 0) wv::lds_st32(ts + S_FLAGS + F_FREE + 4 * buf, gstep + 1);
+      PH(4);  // Intra4x4 chain
 
       // ================= luma write-out ============================================================================
       {
         // bottom line for the row below (ring) or the band below (write-through): lanes 0..3 of row g
         unsigned v = 0;
         if (i < 4) v = wv::lds_u32(tile + TILE_STRIDE * 16 + 8 + 16 * slot + 4 * i);
-        if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ts + S_RINGY + 64 * (g + 1) + 16 * (x & 3) + 4 * i, v);
+        if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ringy(ts, g + 1, x, par) + 4 * i, v);
         if (hasBelow && wv::any(valid && g == gl)) {
           if (valid && g == gl && i < 4) wv::st_sc1((unsigned*)(planeY + (unsigned)((16 * r + 15) * pitchY + 16 * x + 4 * i)), v);
           linePend = true;
@@ -1120,7 +1217,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         }
       }
       wv::wave_sync();
-      PH(13);  // line, copies, flush
+      PH(5);  // line, copies, flush
       // the band's luma is complete once its last stores have been written through
       if (s == G.nSteps - 1 && hasBelow) {
         wv::wait_vm(0);

@@ -6,39 +6,42 @@
 
 namespace dryv {
 
-// 512 threads = 4 teams of a FRONT and a BACK wave; 3 workgroups per CU = 6 waves per SIMD (<= 80 VGPRs), 12 bands per
-// CU, 3072 bands in flight. Measured on the 300-frame 1080p batch (tools/band_variants.sh): 5 teams x 2 workgroups
-// (5 waves per SIMD) 2.25 ms, 4 x 3 (6 per SIMD) 1.99 ms, 4 x 4 and 8 x 2 (8 per SIMD, 64 VGPRs: spilling) 2.42 / 2.45 ms.
+// A workgroup = TEAMS_PER_WG teams of a FRONT, a BACK and a CHROMA wave. The fast build needs 56 VGPRs (8 waves per SIMD
+// fit); the wide build (64-bit residual arithmetic, re-run of a flagged batch only) is compiled for 5 waves per SIMD.
+// Grid shape: tools/band_variants.sh (measurements in DESIGN.md).
 #ifndef DRYV_BAND_WPS
-#define DRYV_BAND_WPS 6   // waves per SIMD the kernel is compiled for (<= 80 VGPRs)
+#define DRYV_BAND_WPS 7   // waves per SIMD the fast build is compiled for (<= 72 VGPRs)
 #endif
 #ifndef DRYV_BAND_WGS_PER_CU
 #define DRYV_BAND_WGS_PER_CU 3
 #endif
 template <bool HAS_I8, bool WIDE>
-__global__ void __launch_bounds__(64 * band::WAVES_PER_WG, DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
+__global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 5 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds[];
   const int ldsBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   constexpr int tEnd = HAS_I8 ? band::T_END_I8 : band::T_END;
   A.waveBase = (int)blockIdx.x * band::WAVES_PER_WG;
   band::build_tables(P, ldsBase, (int)threadIdx.x, (int)blockDim.x, HAS_I8);
-  if (threadIdx.x < 4 * band::TEAMS_PER_WG)  // the teams' ready / free words
-    wv::lds_st32(ldsBase + tEnd + (int)(threadIdx.x >> 2) * band::S_BYTES + band::S_FLAGS + 4 * (int)(threadIdx.x & 3), 0u);
+  if (threadIdx.x < 16 * band::TEAMS_PER_WG)  // the teams' flag words
+    wv::lds_st32(ldsBase + tEnd + (int)(threadIdx.x >> 4) * band::S_BYTES + band::S_FLAGS + 4 * (int)(threadIdx.x & 15), 0u);
   __syncthreads();  // the only workgroup-level synchronisation: the teams are independent from here on
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int ts = ldsBase + tEnd + (wave >> 1) * band::S_BYTES;
-  if (wave & 1) band::band_back<HAS_I8>(P, A, ldsBase, ts);
-  else band::band_front<HAS_I8, WIDE>(P, A, ldsBase, ts);
+  // consecutive waves of a workgroup go to different SIMDs: a team's three waves never share one
+  const int team = wave / band::WAVES_PER_TEAM, role = wave - team * band::WAVES_PER_TEAM;
+  const int ts = ldsBase + tEnd + team * band::S_BYTES;
+  if (role == 1) band::band_back<HAS_I8>(P, A, ldsBase, ts);
+  else if (role == 0) band::band_front<HAS_I8, WIDE>(P, A, ldsBase, ts);
+  else band::band_chroma<HAS_I8, WIDE>(P, A, ldsBase, ts);
 }
 
 size_t band_lds_bytes(bool hasI8) { return (size_t)(hasI8 ? band::T_END_I8 : band::T_END) + (size_t)band::TEAMS_PER_WG * band::S_BYTES; }
 int band_teams_per_block() { return band::TEAMS_PER_WG; }
 int band_blocks_per_cu() { return DRYV_BAND_WGS_PER_CU; }
 
-// Workspace: [task counter | pad to 256][luma progress words][chroma progress words | pad to 256][bottom-row modes]
+// Workspace: [task counter | pad to 256][luma | chroma | modes progress words | pad to 256][bottom-row modes]
 // [diagnostics]
 static size_t band_prog_words(const KParams& P) { return (size_t)P.n_frames * ((P.H + 3) / 4); }
-static size_t band_prog_bytes(const KParams& P) { return (2 * band_prog_words(P) * 4 + 255) & ~(size_t)255; }
+static size_t band_prog_bytes(const KParams& P) { return (3 * band_prog_words(P) * 4 + 255) & ~(size_t)255; }
 size_t band_reset_bytes(const KParams& P) { return 256 + band_prog_bytes(P); }
 size_t band_profile_offset(const KParams& P) {
   return (256 + band_prog_bytes(P) + (size_t)P.n_frames * P.W * P.H * 4 + 255) & ~(size_t)255;
@@ -57,6 +60,7 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   A.taskCounter = (unsigned*)wsb;
   A.progY = (unsigned*)(wsb + 256);
   A.progC = A.progY + band_prog_words(P);
+  A.progM = A.progC + band_prog_words(P);
   A.rowModes = (unsigned*)(wsb + 256 + band_prog_bytes(P));
   A.profile = nullptr;
   A.waveBase = 0;

@@ -95,12 +95,20 @@ static bool g_wide;
 static int wave_index() { return wv::g_wave->index; }
 static void body() {
   using namespace dryv::band;
-  const bool back = (wave_index() & 1) != 0;  // waves 2t / 2t+1 = FRONT / BACK of team t (each team has its own LDS here)
+  const int role = wave_index() % WAVES_PER_TEAM;  // waves 3t .. 3t+2 = FRONT / BACK / CHROMA of team t (each team has its own LDS here)
   const bool i8 = g_P.transform8x8 != 0;
   const int ts = i8 ? T_END_I8 : T_END;
-  if (back) {
+  if (role == 1) {
     if (i8) band_back<true>(g_P, g_A, 0, ts);
     else band_back<false>(g_P, g_A, 0, ts);
+  } else if (role == 2) {
+    if (g_wide) {
+      if (i8) band_chroma<true, true>(g_P, g_A, 0, ts);
+      else band_chroma<false, true>(g_P, g_A, 0, ts);
+    } else {
+      if (i8) band_chroma<true, false>(g_P, g_A, 0, ts);
+      else band_chroma<false, false>(g_P, g_A, 0, ts);
+    }
   } else if (g_wide) {
     if (i8) band_front<true, true>(g_P, g_A, 0, ts);
     else band_front<false, true>(g_P, g_A, 0, ts);
@@ -110,7 +118,7 @@ static void body() {
   }
 }
 
-// n_teams teams (a FRONT and a BACK wave each, sharing one LDS array) claim bands concurrently; the 2 * n_teams waves are
+// n_teams teams (a FRONT, a BACK and a CHROMA wave each, sharing one LDS array) claim bands concurrently; the 3 * n_teams waves are
 // scheduled round-robin from wave `first`, `order` = +1 / -1, each until it polls in vain or finishes.
 extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_frames, const dryv_mb_desc* mbs,
                                     const int16_t* coeffs, uint8_t* yuv, unsigned* status_out, int n_teams, int first,
@@ -118,9 +126,10 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
   int st = dryv::params::build_params(fp, n_frames, &g_P);
   if (st != DRYV_OK) return st;
   if (n_teams < 1) n_teams = 1;
-  const int n_waves = 2 * n_teams;
+  const int WPT = dryv::band::WAVES_PER_TEAM;
+  const int n_waves = WPT * n_teams;
   const int nBands = (g_P.H + 3) / 4;
-  std::vector<unsigned> prog((size_t)2 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H, 0xEEEEEEEEu);
+  std::vector<unsigned> prog((size_t)3 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H, 0xEEEEEEEEu);
   // like the host API: the fast build first; if it flags a block beyond int32 (status bit 1), the batch again with the wide build
   unsigned status[4] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; pass++) {
@@ -128,7 +137,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
     memset(status, 0, sizeof status);
     std::fill(prog.begin(), prog.end(), 0u);
     g_wide = pass == 1;
-    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, modes.data(), &counter, nullptr, 0};
+    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, prog.data() + (size_t)2 * n_frames * nBands, modes.data(), &counter, nullptr, 0};
     wv::g_body = body;
     std::vector<std::unique_ptr<wv::Wave>> waves;
     const int ldsBytes = (g_P.transform8x8 ? dryv::band::T_END_I8 : dryv::band::T_END) + dryv::band::S_BYTES;
@@ -136,13 +145,13 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
     for (int w = 0; w < n_waves; w++) {
       waves.emplace_back(new wv::Wave());
       waves.back()->index = w;
-      waves.back()->st.lds = teamLds[w >> 1].data();
+      waves.back()->st.lds = teamLds[w / WPT].data();
       waves.back()->st.lds_bytes = ldsBytes;
       wv::init_wave(waves.back().get());
       wv::g_emu_cur = &waves.back()->st;
-      if ((w & 1) == 0) {
+      if (w % WPT == 0) {
         dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
-        memset(teamLds[w >> 1].data() + ldsBytes - dryv::band::S_BYTES + dryv::band::S_FLAGS, 0, 16);  // the team's flags
+        memset(teamLds[w / WPT].data() + ldsBytes - dryv::band::S_BYTES + dryv::band::S_FLAGS, 0, 64);  // the team's flags
       }
     }
     int live = n_waves;
@@ -151,12 +160,17 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
       wv::Wave* w = waves[(((first + order * k) % n_waves) + n_waves) % n_waves].get();
       if (w->finished) continue;
       const unsigned before = counter;
-      unsigned long long sum0 = 0;
-      for (unsigned v : prog) sum0 += v;
+      auto progress = [&]() {  // anything a waiting wave could be waiting for: progress words, the teams' flag words
+        unsigned long long t = 0;
+        for (unsigned v : prog) t += v;
+        for (auto& L : teamLds)
+          for (int q = 0; q < 64; q += 4) { unsigned v; memcpy(&v, L.data() + ldsBytes - dryv::band::S_BYTES + dryv::band::S_FLAGS + q, 4); t += v; }
+        return t;
+      };
+      const unsigned long long sum0 = progress();
       const int r = wv::run_slice(w);
       if (r == 2) live--;
-      unsigned long long sum1 = 0;
-      for (unsigned v : prog) sum1 += v;
+      const unsigned long long sum1 = progress();
       if (r == 2 || counter != before || sum1 != sum0) idle_rounds = 0;
       else if (++idle_rounds > (unsigned long long)n_waves * 64) {
         fprintf(stderr, "emu: deadlock: %d waves are polling and nothing makes progress\n", live);

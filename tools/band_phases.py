@@ -17,9 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dryv_amd import _build, abi, synth  # noqa: E402
 
-PHASES = ["F claim+prologue", "F record decode", "F luma residuals", "F hand-off+prefetch", "F record for BACK, modes",
-          "F chroma residuals", "F chroma pred", "F chroma lines+flush", "B wait for record", "B hand-off+top border",
-          "B intra16x16", "B top-right+publish", "B intra4x4 chain", "B line+copies+flush", "-", "-"]
+ROLES = ["FRONT", "BACK", "CHROMA"]   # wave w of a workgroup: role w % 3 (recon_band.hip)
+PHASES = {
+    "FRONT": ["claim+prologue", "record decode", "luma residuals", "hand-off+prefetch", "record for BACK, modes",
+              "desc prefetch, modes hand-off"],
+    "CHROMA": ["task+prologue", "hand-off traffic", "chroma residuals+prefetch", "chroma prediction", "lines+copies+flush"],
+    "BACK": ["wait for record", "top border", "intra16x16", "top-right+publish", "intra4x4 chain", "line+copies+flush"],
+}
 
 
 def main():
@@ -45,16 +49,18 @@ def main():
         ms = C.c_float()
         lib.dryv_recon_last_kernel_ms(h, C.byref(ms))
         tasks = n * 17
-        n_waves = min(5120, (tasks + 4) // 5 * 10)
+        wpw = 3 * lib.dryv_recon_debug_band_teams() if hasattr(lib, "dryv_recon_debug_band_teams") else 9
+        n_waves = 256 * 8 * 12
         out = np.zeros((n_waves, 16), dtype=np.uint64)
         assert lib.dryv_recon_debug_band_phases(h, C.c_int(n_waves), out.ctypes.data_as(C.c_void_p)) == 0
-        tot = out.sum(axis=0).astype(np.float64)
         steps = tasks * 126.0
-        print("== %d frames: instrumented kernel %.3f ms, %d waves, %d band tasks" % (frames, ms.value, n_waves, tasks))
-        for name, v in zip(PHASES, tot):
-            if v > 0:
-                print("  %-26s %8.0f cycles/step" % (name, v / steps))
-        print("  FRONT %.0f cycles/step, BACK %.0f cycles/step" % (tot[:8].sum() / steps, tot[8:].sum() / steps))
+        print("== %d frames: instrumented kernel %.3f ms, %d band tasks" % (frames, ms.value, tasks))
+        wave = np.arange(n_waves)
+        for ri, role in enumerate(ROLES):
+            tot = out[(wave % wpw) % 3 == ri].sum(axis=0).astype(np.float64)
+            print("  %s: %.0f cycles/step" % (role, tot.sum() / steps))
+            for name, v in zip(PHASES[role], tot):
+                print("      %-30s %8.0f" % (name, v / steps))
         lib.dryv_recon_destroy(h)
         del d_m, d_c, d_o
 
