@@ -89,7 +89,7 @@ WV int ringy(int ts, int g, int e, int par) {
 }
 
 #ifndef DRYV_BAND_TEAMS
-#define DRYV_BAND_TEAMS 3   // teams per workgroup (tools/band_variants.sh)
+#define DRYV_BAND_TEAMS 4   // teams per workgroup (tools/band_variants.sh)
 #endif
 constexpr int TEAMS_PER_WG = DRYV_BAND_TEAMS;
 constexpr int WAVES_PER_TEAM = 3;  // FRONT, BACK, CHROMA
@@ -114,6 +114,19 @@ constexpr unsigned TASK_END = 0xFFFFFFFFu;
   } while (0)
 #else
 #define PH(k) do { } while (0)
+#endif
+// -DDRYV_BAND_TIMELINE (tools/band_timeline.py): per band task, 100 MHz timestamps of the claim (FRONT) and of BACK's
+// first and last step, behind the trace records
+#if defined(DRYV_BAND_TIMELINE) && !defined(DRYV_EMU)
+#define TLINE(task, k, val)                                                                                   \
+  do {                                                                                                        \
+    if (lane0 == 0 && A.profile)                                                                              \
+      (A.profile + (size_t)65536 * (BAND_NPH + 4))[(size_t)(task) * 4 + (k)] = (unsigned long long)(val);   \
+  } while (0)
+#define TNOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define TLINE(task, k, val) do { } while (0)
+#define TNOW() 0
 #endif
 // breadcrumbs: word k of this wave's 8-word trace record (behind the phase sums), written through so that a host
 // thread can read them while the kernel is still running
@@ -322,12 +335,12 @@ WV void residual_pass(const u32x4 c0, const u32x4 c1, int lsAddr, int qp, bool u
 
 // lane i ^ 4 and i ^ 8 inside a 16-lane DPP row
 WV int xor4(int v, bool bit2) {
-  const int a = wv::dpp<DPP_ROW_ROR(12)>(v, v), b = wv::dpp<DPP_ROW_ROR(4)>(v, v);
+  const int a = wv::dppx<DPP_ROW_ROR(12)>(v), b = wv::dppx<DPP_ROW_ROR(4)>(v);
   return bit2 ? b : a;
 }
-WV int xor8(int v) { return wv::dpp<DPP_ROW_ROR(8)>(v, v); }
-WV int xor1(int v) { return wv::dpp<DPP_QUAD(1, 0, 3, 2)>(v, v); }
-WV int xor2(int v) { return wv::dpp<DPP_QUAD(2, 3, 0, 1)>(v, v); }
+WV int xor8(int v) { return wv::dppx<DPP_ROW_ROR(8)>(v); }
+WV int xor1(int v) { return wv::dppx<DPP_QUAD(1, 0, 3, 2)>(v); }
+WV int xor2(int v) { return wv::dppx<DPP_QUAD(2, 3, 0, 1)>(v); }
 
 // One reconstructed row of 4 pixels: prediction as two u16 pairs, residual as two i16 pairs
 WV unsigned recon_row(unsigned p01, unsigned p23, unsigned r01, unsigned r23) {
@@ -428,6 +441,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       break;
     }
     TRACE(0, task + 1u);
+    TLINE(task, 0, TNOW());
+    TLINE(task, 3, A.waveBase + (int)(threadIdx.x >> 6));
     const BandGeo G = band_geo(task, nF, W, H);
     const int r0 = G.r0, nR = G.nR, gl = G.gl, nSteps = G.nSteps;
     const bool hasAbove = G.hasAbove, hasBelow = G.hasBelow;
@@ -618,7 +633,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         int M = 2;
 #pragma unroll
         for (int itr = 0; itr < 7; itr++) {
-          int Am = wv::dpp<DPP_QUAD(0, 0, 1, 2)>(M, M);
+          int Am = wv::dppx<DPP_QUAD(0, 0, 1, 2)>(M);
           if (rbx == 0) Am = mbA ? Lb : 2;
           const int Bm = wv::dpp<DPP_ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
           const int pm = unav ? 2 : min(Am, Bm);
@@ -716,31 +731,35 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     unsigned* const myProg = A.progC + (size_t)G.f * nBands + G.b;
     const unsigned* const upProg = myProg - 1;
 
-    // software pipeline as in FRONT: first record word and coefficients one step ahead
+    // Residuals are computed for two steps at a time, lanes 0..31 the even step's 32 blocks, lanes 32..63 the odd step's
+    // (a residual pass costs the same for 32 lanes as for 64); prediction then runs on the half whose step it is.
+    // Software pipeline as in FRONT: first record word and coefficients one pair of steps ahead.
     auto mb_index = [&](int step, int g) -> unsigned {  // within the frame
       const int x = min(max(step - 2 * g, 0), W - 1);
       return (unsigned)(min(r0 + g, H - 1) * W + x);
     };
     auto load_kind = [&](int step) -> unsigned {
       const int l = wv::opaque(lane0);
-      return *(const unsigned*)(mbsF + 16u * mb_index(step, (l >> 3) & 3));
+      return *(const unsigned*)(mbsF + 16u * mb_index(step + (l >> 5), (l >> 3) & 3));
     };
     u32x4 cB0, cB1;
     int dcB;
     cB0 = cB1 = u32x4{0, 0, 0, 0};
     dcB = 0;
-    auto load_coefs_chroma = [&](int step) {
+    auto load_coefs_chroma = [&](int step) {  // `step` even: the pair (step, step + 1)
       const int l = wv::opaque(lane0);
-      if (l < 32) {
-        const int cpl = (l >> 2) & 1, cblk = l & 3;
-        const unsigned mo = mb_index(step, (l >> 3) & 3) * 768u;
-        const unsigned offc = 2u * (unsigned)(259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
-        cB0 = wv::ld_u128_a2(coefF + (mo + offc));
-        cB1 = wv::ld_u128_a2(coefF + (mo + offc + 16u));
-        dcB = *(const int16_t*)(coefF + (mo + 2u * (unsigned)(256 + 64 * cpl + cblk)));
-      }
+      const int cpl = (l >> 2) & 1, cblk = l & 3;
+      const unsigned mo = mb_index(step + (l >> 5), (l >> 3) & 3) * 768u;
+      const unsigned offc = 2u * (unsigned)(259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
+      cB0 = wv::ld_u128_a2(coefF + (mo + offc));
+      cB1 = wv::ld_u128_a2(coefF + (mo + offc + 16u));
+      dcB = *(const int16_t*)(coefF + (mo + 2u * (unsigned)(256 + 64 * cpl + cblk)));
     };
-    unsigned kN1 = load_kind(0);
+    unsigned kN1 = load_kind(0);  // first record word of this lane's macroblock in the next pair of steps
+    unsigned dC = 0;              // ... in the current pair
+    unsigned rB[8];               // this lane's block residual (current pair)
+#pragma unroll
+    for (int k = 0; k < 8; k++) rB[k] = 0;
     load_coefs_chroma(0);
     PH(0);  // task, prologue loads
     unsigned upKnown = 0;    // what this wave knows of the band above's chroma progress
@@ -749,15 +768,17 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     bool linePend = false;   // bottom lines of the band's last row were stored in the previous step, not yet published
 
     for (int s = 0; s < nSteps; s++) {
-      const unsigned dC = kN1;
+      const bool evenStep = (s & 1) == 0;
+      if (evenStep) dC = kN1;
       const int lane = wv::opaque(lane0);
       const int g = lane >> 4, i = lane & 15;                                            // write-out organisation: row g
-      const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;           // lane-per-block (lanes 0..31)
+      const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;           // lane-per-block, step sL
       const int ccx = cblk & 1, ccy = cblk >> 1;
-      const bool chromaLane = lane < 32;
+      const int sL = (s & ~1) + (lane >> 5);      // the step this lane's block belongs to
+      const bool chromaLane = sL == s;
       const int r = r0 + g, rC = r0 + gc;
       const bool mbBC = rC > 0;
-      const int x = s - 2 * g, xC = s - 2 * gc;
+      const int x = s - 2 * g, xC = sL - 2 * gc;
       const bool valid = g < nR && x >= 0 && x < W, validC = gc < nR && xC >= 0 && xC < W;
       const bool mbAC = xC > 0;
       const int slot = s & 1;  // (x & 1 for every row)
@@ -801,8 +822,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       PH(1);  // hand-off traffic
 
       // ================= chroma residuals ==========================================================================
-      unsigned rB[8];
-      {
+      if (evenStep) {
         // chroma DC 2x2 (8.5.11, trans_chroma.rs:369-415) over the four block lanes of a plane, then the AC pass.
         // The LevelScale table is luma's (quirk Q3).
         const int qc = (int)wv::lds_u8(ldsBase + T_QPC + 52 * cpl + qpC);
@@ -819,9 +839,9 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
 #pragma unroll
           for (int k = 0; k < 8; k++) rB[k] = 0;
         }
+        load_coefs_chroma(s + 2);
+        kN1 = load_kind(s + 2);
       }
-      load_coefs_chroma(s + 1);
-      kN1 = load_kind(s + 1);
       if (fetchLane) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * li, lineV);
       wv::wave_sync();
       PH(2);  // chroma residuals, prefetch
@@ -996,6 +1016,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     if (s == 0) {
       G = band_geo(task, nF, W, H);
       par = wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 24));
+      TLINE(task, 1, TNOW());
       planeY = A.yuv + (size_t)G.f * frameBytes;
       myProg = A.progY + (size_t)G.f * nBands + G.b;
       linePend = false;
@@ -1157,14 +1178,18 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           const int b2 = (int)wv::lds_u8(org + (int)(en.y >> 24));                                                \
           const unsigned top = wv::lds_u32(org + 1);                                                              \
           const int l0 = (int)wv::lds_u8(org + TILE_STRIDE), l1 = (int)wv::lds_u8(org + 2 * TILE_STRIDE);         \
-          const int l2 = (int)wv::lds_u8(org + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(org + 4 * TILE_STRIDE);     \
+          const int l2 = (int)wv::lds_u8(org + 3 * TILE_STRIDE), l3r = (int)wv::lds_u8(org + 4 * TILE_STRIDE);     \
+          /* (the last load issued: the compiler must not sink the DC samples' loads into a branch of their own) */ \
+          const int l3 = wv::opaque(l3r);                                                                         \
           int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                       \
           int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                       \
           {                                                                                                       \
             /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch) */ \
-            const int sumT = (int)wv::sad4(top), sumL = l0 + l1 + l2 + l3;                                        \
             const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA;                                             \
-            const int dc = (topAv && leftAv) ? (sumT + sumL + 4) >> 3 : leftAv ? (sumL + 2) >> 2 : topAv ? (sumT + 2) >> 2 : 128; \
+            const int sm = (topAv ? (int)wv::sad4(top) : 0) + (leftAv ? l0 + l1 + l2 + l3 : 0);                   \
+            const int both = (topAv && leftAv) ? 1 : 0;                                                           \
+            int dc = (sm + 2 + 2 * both) >> (2 + both);                                                           \
+            if (!topAv && !leftAv) dc = 128;                                                                      \
             if (en.x & 32u) pa = pb = dc;                                                                         \
           }                                                                                                       \
           const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));              \
@@ -1223,6 +1248,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         wv::wait_vm(0);
         if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
       }
+      if (s == G.nSteps - 1) TLINE(task, 2, TNOW());
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
   if (lane0 == 0 && A.profile)

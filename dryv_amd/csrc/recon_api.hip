@@ -81,8 +81,8 @@ int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
 
 size_t workspace_bytes(const KParams& P) {
   size_t b = std::max(dryv::recon_workspace_bytes(P.W, P.H, P.n_frames), dryv::band_workspace_bytes(P));
-#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
-  b = dryv::band_profile_offset(P) + (size_t)65536 * 16 * 8 + (size_t)65536 * 32;
+#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE) || defined(DRYV_BAND_TIMELINE)
+  b = dryv::band_profile_offset(P) + (size_t)65536 * 16 * 8 + (size_t)65536 * 32 * 2;  /* phases, trace, timeline */
 #endif
   return b;
 }
@@ -96,8 +96,8 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   if (grid < 1) grid = 1;
   e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
-#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
-  e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_profile_offset(P), 0, (size_t)65536 * 16 * 8 + (size_t)65536 * 32, ctx->stream);
+#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE) || defined(DRYV_BAND_TIMELINE)
+  e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_profile_offset(P), 0, (size_t)65536 * 16 * 8 + (size_t)65536 * 32 * 2, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(profile)");
 #endif
   e = hipEventRecord(ctx->ev_start, ctx->stream);
@@ -464,6 +464,16 @@ int dryv_recon_debug_phases(dryv_recon_ctx* ctx, const dryv_frame_params* fp, ui
 }
 #endif
 
+#if defined(DRYV_BAND_TIMELINE)
+/* diagnostic build only: per band task of the last launch 4 x u64 (claim, BACK's first step, BACK's last step: 100 MHz
+   ticks; wave index) */
+int dryv_recon_debug_band_timeline(dryv_recon_ctx* ctx, int n_tasks, unsigned long long* out) {
+  if (!ctx || !out || n_tasks > 65536 || !ctx->d_work) return DRYV_E_INVALID;
+  hipError_t e = hipMemcpy(out, (unsigned char*)ctx->d_work + dryv::band_profile_offset(ctx->last_P) + (size_t)65536 * (16 * 8 + 32),
+                           (size_t)n_tasks * 32, hipMemcpyDeviceToHost);
+  return e == hipSuccess ? DRYV_OK : DRYV_E_DEVICE;
+}
+#endif
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
 /* diagnostic build only: reads n_waves x 8 trace words and `n_prog` progress words while the kernel may still be running
    (own stream) */

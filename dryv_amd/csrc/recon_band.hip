@@ -10,10 +10,10 @@ namespace dryv {
 // fit); the wide build (64-bit residual arithmetic, re-run of a flagged batch only) is compiled for 5 waves per SIMD.
 // Grid shape: tools/band_variants.sh (measurements in DESIGN.md).
 #ifndef DRYV_BAND_WPS
-#define DRYV_BAND_WPS 7   // waves per SIMD the fast build is compiled for (<= 72 VGPRs)
+#define DRYV_BAND_WPS 6   // waves per SIMD the fast build is compiled for (<= 80 VGPRs)
 #endif
 #ifndef DRYV_BAND_WGS_PER_CU
-#define DRYV_BAND_WGS_PER_CU 3
+#define DRYV_BAND_WGS_PER_CU 2
 #endif
 template <bool HAS_I8, bool WIDE>
 __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 5 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
@@ -64,7 +64,7 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   A.rowModes = (unsigned*)(wsb + 256 + band_prog_bytes(P));
   A.profile = nullptr;
   A.waveBase = 0;
-#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
+#if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE) || defined(DRYV_BAND_TIMELINE)
   A.profile = (unsigned long long*)(wsb + band_profile_offset(P));
 #endif
   const bool i8 = P.transform8x8 != 0;

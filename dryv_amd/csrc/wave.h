@@ -33,6 +33,10 @@ WV void wave_sync() {
 }
 template <int CTRL>
 WV int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false); }
+// for controls under which every lane has a source (quad_perm, row_ror): no `old` value, so that the compiler can fold the
+// move into the instruction that uses it
+template <int CTRL>
+WV int dppx(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xF, 0xF, true); }
 WV int bperm(int v, int srcLane) { return __builtin_amdgcn_ds_bpermute(srcLane << 2, v); }
 WV int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 WV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -162,6 +166,8 @@ WV int dpp(int old, int src) {
   emu_barrier("dpp2");
   return r;
 }
+template <int CTRL>
+WV int dppx(int src) { return dpp<CTRL>(src, src); }
 WV int bperm(int v, int srcLane) {
   const int l = lane_id();
   g_emu.xbuf[l] = v;
