@@ -60,8 +60,21 @@ constexpr int T_LS8 = 1280;   // u16 [6][64]    (HAS_I8 only)
 constexpr int T_END_I8 = 2048;
 
 // ---- per-team scratch in LDS (byte offsets from the team's base) ---------------------------------------------
+// Output staging: a row's pixels are flushed to global memory NSY (luma) / NSC (chroma) macroblocks at a time, as
+// 16 x NSY / 8 x NSC contiguous bytes per pixel row: the wider the segment, the fewer partial lines memory sees.
+#ifndef DRYV_BAND_NSY
+#define DRYV_BAND_NSY 2
+#endif
+#ifndef DRYV_BAND_NSC
+#define DRYV_BAND_NSC 2
+#endif
+constexpr int NSY = DRYV_BAND_NSY, NSC = DRYV_BAND_NSC;
+static_assert((NSY == 2 || NSY == 4 || NSY == 8) && (NSC == 2 || NSC == 4 || NSC == 8), "staging widths");
+// luma: NSY / 2 tiles of two macroblocks per row (the Intra4x4 table holds tile offsets in 8 bits: the stride stays 40)
 constexpr int TILE_STRIDE = 40;
 constexpr int TILE_BYTES = 704;  // 17 rows x 40 + 8 (row y = -1 of slot 1 reaches 8 bytes into row y = 0), 64-aligned
+constexpr int NP = NSY / 2;
+constexpr int CW = 8 * NSC;      // chroma staging: bytes per pixel row
 // FRONT -> BACK, double-buffered by the parity of the team's global step count
 constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [blkIdx][y][x]
 constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       Intra4x4 table row per chain step and block half
@@ -70,20 +83,22 @@ constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2] (global step count + 1
                                  //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks)
 constexpr int F_READY = 0, F_FREE = 8, F_TASKS = 16, F_HEAD = 32, F_TAILC = 36;
 // BACK (+ FRONT writes row 0 of the luma ring: lines fetched from the band above)
-constexpr int S_TILE = 4416;     // u8  [4][TILE_BYTES]  luma: row j = y + 1, column 8 + 16 * (x & 1) + xr
-constexpr int S_RINGY = S_TILE + 4 * TILE_BYTES;  // bottom luma lines of the row above: row 0 [2][8][16], rows 1..3 [4][16]
+constexpr int S_TILE = 4416;     // u8  [4][NP][TILE_BYTES]  luma: tile (x >> 1) % NP, row j = y + 1, column 8 + 16 * (x & 1) + xr
+constexpr int S_RINGY = S_TILE + 4 * NP * TILE_BYTES;  // bottom luma lines of the row above: row 0 [2][8][16], rows 1..3 [4][16]
 constexpr int S_LEFTY = S_RINGY + 448;            // u8 [4][16]     column 15 of the macroblock to the left
 // CHROMA
-constexpr int S_STC = S_LEFTY + 64;               // u8 [4][2][8][16] chroma staging, two macroblocks wide
-constexpr int S_RINGC = S_STC + 1024;             // [4][4][16]  bottom chroma lines of the row above: Cb[8] Cr[8]
+constexpr int S_STC = S_LEFTY + 64;               // u8 [4][2][8][CW] chroma staging, NSC macroblocks wide
+constexpr int S_RINGC = S_STC + 64 * CW;             // [4][4][16]  bottom chroma lines of the row above: Cb[8] Cr[8]
 constexpr int RINGC_ROW = 64, RINGC_ENT = 16;
 constexpr int S_LEFTC = S_RINGC + 256;            // u8 [4][2][8]
 // FRONT
 constexpr int S_RINGM = S_LEFTC + 64;             // u32 [4][4]  bottom-row modes of the row above
-constexpr int S_BYTES = 9152;                     // (64-byte multiple)
+constexpr int S_BYTES = (S_RINGM + 64 + 63) & ~63;
 static_assert(S_RINGM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
+// the luma tile of macroblock x of row g
+WV int tile_of(int ts, int g, int x) { return ts + S_TILE + TILE_BYTES * (NP * g + ((x >> 1) & (NP - 1))); }
 WV int ringy(int ts, int g, int e, int par) {
   return g == 0 ? ts + S_RINGY + 128 * par + 16 * (e & 7) : ts + S_RINGY + 256 + 64 * (g - 1) + 16 * (e & 3);
 }
@@ -498,6 +513,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     unsigned flagV = 0;      // the band above's progress words, fetched during the previous step
     bool flagPend = false;
     bool linePend = false;   // bottom-row modes of the band's last row were stored in the previous step, not yet published
+    unsigned lineN = 0;      // the band above's words of macroblock s+1, requested during the previous step (haveN)
+    bool haveN = false;
 
     for (int s = 0; s < nSteps; s++, gstep++) {
       TRACE(1, s + 1);
@@ -530,6 +547,9 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         qp = 0;
       }
       const bool mbA = x > 0, mbC = mbB && (x + 1 < W);
+      // the record of step s+1, the first record word of step s+2: requested now, a whole step before they are needed
+      dN1 = load_desc(s + 1);
+      kN2 = load_kind(s + 2);
 
       PH(1);  // record decode
       // ================= residuals ================================================================================
@@ -575,10 +595,16 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         linePend = false;
       }
       // lanes 0..4: macroblock s+1 of the band above's last row (0..3 bottom luma line, 4 modes); lanes 16..20:
-      // macroblock 0 at step 0
+      // macroblock 0 at step 0. When the band above is far enough ahead, macroblock s+2 is requested as well and kept in
+      // a register until the next step: the request then has a whole step to come back (haveN / lineN).
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
       const bool fetchLane = needUp && li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+      auto fetch_up = [&](int mb) -> unsigned {
+        if (li < 4) return wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mb + 4 * li)));
+        return wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mb)));
+      };
+      bool haveNext = false;
       if (needUp) {
         // the band above must have finished macroblock s+1 (luma: BACK's neighbour C; modes) before they are fetched.
         // Its progress words are read one step ahead (flagV), so this normally costs nothing; otherwise poll.
@@ -587,14 +613,17 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         upKnown = poll_progress(upProgY, upProgM, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
         wv::compiler_fence();
         if (fetchLane) {
-          if (li < 4) lineV = wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mbx + 4 * li)));
-          else lineV = wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mbx)));
+          if (haveN && lane < 16) lineV = lineN;
+          else lineV = fetch_up(mbx);
         }
+        haveNext = s + 2 < W && upKnown >= (unsigned)(s + 3);
+        if (haveNext && lane < 16 && li < 5) lineN = fetch_up(s + 2);
         if (upKnown < (unsigned)W) {
           flagV = wv::ld_sc1(lane < 32 ? upProgY : upProgM);
           flagPend = true;
         }
       }
+      haveN = haveNext;
       load_coefs_luma(s + 1, kN1);  // (into the registers the residual pass has just freed)
       PH(3);  // hand-off traffic, coefficient prefetch
 
@@ -663,9 +692,6 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       if (lane == 0) wv::lds_st32(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);  // the record is complete
       PH(4);  // record for BACK, modes
 
-      // the record of step s+1, the first record word of step s+2
-      dN1 = load_desc(s + 1);
-      kN2 = load_kind(s + 2);
       // bottom-row modes for the row below (ring) or the band below (write-through)
       {
         unsigned m4 = (unsigned)Mcur << (8 * (i & 3));
@@ -679,7 +705,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       }
       Mprev = valid ? Mcur : 2;
       wv::wave_sync();
-      PH(5);  // prefetch, modes hand-off
+      PH(5);  // modes hand-off
     }
     // the band's modes are complete once the last store has been written through
     if (hasBelow) {
@@ -766,6 +792,8 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
     bool flagPend = false;
     bool linePend = false;   // bottom lines of the band's last row were stored in the previous step, not yet published
+    unsigned lineN = 0;      // the band above's line words of macroblock s+1, requested during the previous step
+    bool haveN = false;
 
     for (int s = 0; s < nSteps; s++) {
       const bool evenStep = (s & 1) == 0;
@@ -781,7 +809,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       const int x = s - 2 * g, xC = sL - 2 * gc;
       const bool valid = g < nR && x >= 0 && x < W, validC = gc < nR && xC >= 0 && xC < W;
       const bool mbAC = xC > 0;
-      const int slot = s & 1;  // (x & 1 for every row)
+      const int slot = x & (NSC - 1), slotC = xC & (NSC - 1);  // staging columns
       const bool needUp = hasAbove && s < W;
       unsigned lineV = 0;
       // the record checks FRONT makes (it also reports them): an unsupported record reconstructs as zero
@@ -801,24 +829,33 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
         linePend = false;
       }
-      // lanes 0..3: bottom lines of macroblock s+1 of the band above (0..1 Cb, 2..3 Cr); lanes 16..19: macroblock 0 at step 0
+      // lanes 0..3: bottom lines of macroblock s+1 of the band above (0..1 Cb, 2..3 Cr); lanes 16..19: macroblock 0 at
+      // step 0; macroblock s+2 is requested a step early when the band above is far enough ahead (as in FRONT)
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
       const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+      auto fetch_up = [&](int mb) -> unsigned {
+        const unsigned off = (li < 2 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mb + 4 * (li & 1));
+        return wv::ld_sc1((const unsigned*)(planeY + off));
+      };
+      bool haveNext = false;
       if (needUp) {
         if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
         flagPend = false;
         upKnown = poll_progress(upProg, upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
         wv::compiler_fence();
         if (fetchLane) {
-          const unsigned off = (li < 2 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mbx + 4 * (li & 1));
-          lineV = wv::ld_sc1((const unsigned*)(planeY + off));
+          if (haveN && lane < 16) lineV = lineN;
+          else lineV = fetch_up(mbx);
         }
+        haveNext = s + 2 < W && upKnown >= (unsigned)(s + 3);
+        if (haveNext && lane < 16 && li < 4) lineN = fetch_up(s + 2);
         if (upKnown < (unsigned)W) {
           flagV = wv::ld_sc1(upProg);
           flagPend = true;
         }
       }
+      haveN = haveNext;
       PH(1);  // hand-off traffic
 
       // ================= chroma residuals ==========================================================================
@@ -918,9 +955,9 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
           for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
         }
         if (chromaLane) {
-          const int st = ts + S_STC + 256 * gc + 128 * cpl + 16 * (4 * ccy) + 8 * slot + 4 * ccx;
+          const int st = ts + S_STC + 16 * CW * gc + 8 * CW * cpl + CW * (4 * ccy) + 8 * slotC + 4 * ccx;
 #pragma unroll
-          for (int k = 0; k < 4; k++) wv::lds_st32(st + 16 * k, recon_row(p01[k], p23[k], rB[2 * k], rB[2 * k + 1]));
+          for (int k = 0; k < 4; k++) wv::lds_st32(st + CW * k, recon_row(p01[k], p23[k], rB[2 * k], rB[2 * k + 1]));
         }
       }
 
@@ -939,7 +976,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       // bottom chroma lines for the row below (ring) or the band below (write-through): lanes 0..1 of row g Cb, 2..3 Cr
       {
         unsigned v = 0;
-        if (i < 4) v = wv::lds_u32(ts + S_STC + 256 * g + 128 * (i >> 1) + 16 * 7 + 8 * slot + 4 * (i & 1));
+        if (i < 4) v = wv::lds_u32(ts + S_STC + 16 * CW * g + 8 * CW * (i >> 1) + CW * 7 + 8 * slot + 4 * (i & 1));
         if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ts + S_RINGC + RINGC_ROW * (g + 1) + RINGC_ENT * (x & 3) + 4 * i, v);
         if (hasBelow && wv::any(valid && g == gl)) {  // the band's last row: written through for the band below
           if (valid && g == gl && i < 4) {
@@ -952,21 +989,29 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       // left neighbour copy: chroma column 7
       {
         const int pl = i >> 3, yy = i & 7;
-        const unsigned c = wv::lds_u8(ts + S_STC + 256 * g + 128 * pl + 16 * yy + 8 * slot + 7);
+        const unsigned c = wv::lds_u8(ts + S_STC + 16 * CW * g + 8 * CW * pl + CW * yy + 8 * slot + 7);
         wv::lds_st8(ts + S_LEFTC + 16 * g + 8 * pl + yy, c);
       }
       wv::wave_sync();
-      // flush the staged rows: every second macroblock, or at the end of a row: 16 contiguous bytes per pixel row.
+      // flush the staged rows: every NSC-th macroblock, or at the end of a row: 8 * NSC contiguous bytes per pixel row.
       // The bottom lines of a band that has a band below were already written through.
-      if (wv::any(valid && (slot == 1 || x == W - 1))) {
-        const int fg = lane >> 4, pl = (lane >> 3) & 1, fy = lane & 7;
-        const int fx = s - 2 * fg, xp = fx & ~1;
-        const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && !(hasBelow && fg == gl && fy == 7);
-        const u32x4 v = wv::lds_u128(ts + S_STC + 256 * fg + 128 * pl + 16 * fy);
-        uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp));
-        if (ok) {
-          if (xp + 1 <= fx) wv::st_g128(dst, v);
-          else wv::st_g64(dst, u32x2{v.x, v.y});
+      if (wv::any(valid && (slot == NSC - 1 || x == W - 1))) {
+        constexpr int LR = 8 * NSC;  // lanes per macroblock row: 2 planes x 8 pixel rows x NSC / 2 segments of 16 bytes
+#pragma unroll
+        for (int it = 0; it < NSC / 2; it++) {
+          const int q = lane + 64 * it;
+          const int fg = q / LR, w = q % LR;
+          const int pl = w / (LR / 2), fy = (w / (NSC / 2)) & 7, seg = w % (NSC / 2);
+          const int fx = s - 2 * fg, xp = fx & ~(NSC - 1);
+          const bool ok = fg < nR && fx >= 0 && fx < W && ((fx & (NSC - 1)) == NSC - 1 || fx == W - 1) && xp + 2 * seg <= fx &&
+                          !(hasBelow && fg == gl && fy == 7);
+          if (NSC >= 8 && !wv::any(ok)) continue;  // (one macroblock row per iteration)
+          const u32x4 v = wv::lds_u128(ts + S_STC + 16 * CW * fg + 8 * CW * pl + CW * fy + 16 * seg);
+          uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp + 16 * seg));
+          if (ok) {
+            if (xp + 2 * seg + 1 <= fx) wv::st_g128(dst, v);
+            else wv::st_g64(dst, u32x2{v.x, v.y});
+          }
         }
       }
       wv::wave_sync();
@@ -1029,14 +1074,14 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     const int g = lane >> 4, i = lane & 15;
     const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
     const int ch = (i >> 3) & 1, cp = i & 7;                                          // Intra4x4 chain: block half, pixel pair
-    const int tile = ts + S_TILE + TILE_BYTES * g;
     const int r = r0 + g;
     const bool rowOk = g < nR;
     const bool mbB = r > 0;
     const int x = s - 2 * g;
     const bool valid = rowOk && x >= 0 && x < W;
     const bool mbA = x > 0;
-    const int slot = s & 1;  // (x & 1 for every row)
+    const int slot = x & 1;
+    const int tile = tile_of(ts, g, x);
     const unsigned info = wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g);
     const int kind = (int)(info & 0xffu), i16mode = (int)((info >> 8) & 0xffu);
     PH(0);  // wait for the record
@@ -1223,22 +1268,24 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       {
         const unsigned v = wv::lds_u8(tile + TILE_STRIDE * (i + 1) + 8 + 16 * slot + 15);
         wv::lds_st8(ts + S_LEFTY + 16 * g + i, v);
-        if (slot == 1) wv::lds_st8(tile + TILE_STRIDE * (i + 1) + 7, v);
+        if (slot == 1) wv::lds_st8(tile_of(ts, g, x + 1) + TILE_STRIDE * (i + 1) + 7, v);
       }
       wv::wave_sync();
-      // flush the staged rows: every second macroblock, or at the end of a row: 32 contiguous bytes per pixel row.
+      // flush the staged rows: every NSY-th macroblock, or at the end of a row: 16 * NSY contiguous bytes per pixel row.
       // The bottom line of a band that has a band below was already written through.
-      if (wv::any(valid && (slot == 1 || x == W - 1))) {
+      if (wv::any(valid && ((x & (NSY - 1)) == NSY - 1 || x == W - 1))) {
+        constexpr int LR = 16 * NSY;  // lanes per macroblock row: 16 pixel rows x NSY segments of 16 bytes
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
+        for (int it = 0; it < NSY; it++) {
           const int q = lane + 64 * it;
-          const int fg = q >> 5, fy = (q >> 1) & 15, half = q & 1;
-          const int fx = s - 2 * fg, xp = fx & ~1;
-          const bool ok = fg < nR && fx >= 0 && fx < W && (slot == 1 || fx == W - 1) && xp + half <= fx &&
+          const int fg = q / LR, fy = (q / NSY) & 15, seg = q % NSY;
+          const int fx = s - 2 * fg, xp = fx & ~(NSY - 1);
+          const bool ok = fg < nR && fx >= 0 && fx < W && ((fx & (NSY - 1)) == NSY - 1 || fx == W - 1) && xp + seg <= fx &&
                           !(hasBelow && fg == gl && fy == 15);
-          const int src = ts + S_TILE + TILE_BYTES * fg + TILE_STRIDE * (fy + 1) + 8 + 16 * half;
+          if (NSY >= 4 && !wv::any(ok)) continue;  // (one macroblock row, or half of one, per iteration)
+          const int src = ts + S_TILE + TILE_BYTES * (NP * fg + (seg >> 1)) + TILE_STRIDE * (fy + 1) + 8 + 16 * (seg & 1);
           const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
-          if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + half)), u32x4{lo.x, lo.y, hi.x, hi.y});
+          if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + seg)), u32x4{lo.x, lo.y, hi.x, hi.y});
         }
       }
       wv::wave_sync();

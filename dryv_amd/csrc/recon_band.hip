@@ -70,6 +70,12 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   const bool i8 = P.transform8x8 != 0;
   const size_t ldsBytes = band_lds_bytes(i8);
   const dim3 g(grid), b(64 * band::WAVES_PER_WG);
+  if (ldsBytes > 65536) {  // (build variants with wide staging: beyond the default dynamic LDS limit)
+    const void* fn = i8 ? (wide ? (const void*)band_kernel<true, true> : (const void*)band_kernel<true, false>)
+                        : (wide ? (const void*)band_kernel<false, true> : (const void*)band_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e != hipSuccess) return e;
+  }
   if (i8 && wide) hipLaunchKernelGGL((band_kernel<true, true>), g, b, ldsBytes, stream, P, A);
   else if (i8) hipLaunchKernelGGL((band_kernel<true, false>), g, b, ldsBytes, stream, P, A);
   else if (wide) hipLaunchKernelGGL((band_kernel<false, true>), g, b, ldsBytes, stream, P, A);

@@ -8,29 +8,33 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libdryv_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-_lib = None
+_libs = {}
 
 
-def build(force=False):
+def build(force=False, defs=()):
+    """defs: extra -D flags (the kernel's build-time variants, e.g. staging widths); one library per set."""
+    SO = os.path.join(HERE, "libdryv_emu%s.so" % "".join("_" + d.replace("-D", "").replace("=", "") for d in defs))
     csrc = os.path.join(HERE, "..", "..", "dryv_amd", "csrc")
     deps = [os.path.join(HERE, "band_emu.cpp")] + [os.path.join(csrc, f) for f in
                                                     ("band_kernel.h", "wave.h", "kparams.h", "recon_params.h")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         r = subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DDRYV_EMU", "-Wall",
-                            "-Wno-unused-function", "-o", SO, deps[0]], stdout=subprocess.PIPE,
+                            "-Wno-unused-function", *defs, "-o", SO, deps[0]], stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("emulator build failed:\n" + r.stdout)
     return SO
 
 
-def reconstruct(fp, n_frames, mbs, coeffs, n_teams=1, first=0, order=1):
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.dryv_emu_reconstruct.restype = C.c_int
-        _lib.dryv_emu_reconstruct.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                              C.c_int, C.c_int, C.c_int]
+def reconstruct(fp, n_frames, mbs, coeffs, n_teams=1, first=0, order=1, defs=()):
+    defs = tuple(defs)
+    if defs not in _libs:
+        lib = C.CDLL(build(defs=defs))
+        lib.dryv_emu_reconstruct.restype = C.c_int
+        lib.dryv_emu_reconstruct.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int]
+        _libs[defs] = lib
+    _lib = _libs[defs]
     mbs = np.ascontiguousarray(mbs)
     coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
     n_mbs = n_frames * fp.pic_width_in_mbs * fp.pic_height_in_mbs

@@ -20,9 +20,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import emu  # noqa: E402
 
 
-def check(fp, frames, mbs, co, expect_status=0, teams=1, first=0, order=1):
+def check(fp, frames, mbs, co, expect_status=0, teams=1, first=0, order=1, defs=()):
     st, want = oracle.reconstruct(fp, frames, mbs, co)
-    st2, got = emu.reconstruct(fp, frames, mbs, co, teams, first, order)
+    st2, got = emu.reconstruct(fp, frames, mbs, co, teams, first, order, defs=defs)
     assert (st != 0) == (expect_status != 0)
     assert (st2 != 0) == (expect_status != 0)
     W, H = fp.pic_width_in_mbs, fp.pic_height_in_mbs
@@ -69,6 +69,17 @@ def test_emulated_teams_run_concurrently(geo):
     fp = abi.make_frame_params(W, H)
     mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0), 100, 0, frames)
     check(fp, frames, mbs, co, teams=teams, first=first, order=order)
+
+
+@pytest.mark.parametrize("nsy,nsc", [(2, 2), (8, 4), (4, 2), (2, 8)])
+def test_emulated_staging_widths(nsy, nsc):
+    """The output staging width (macroblocks per flushed row segment) is a build-time choice; every choice must give
+    the same pictures, ragged right edges included (widths 11 and 17 are multiples of none of them)."""
+    defs = ("-DDRYV_BAND_NSY=%d" % nsy, "-DDRYV_BAND_NSC=%d" % nsc)
+    for W, H, frames, teams in ((11, 6, 2, 3), (17, 5, 1, 2), (3, 4, 2, 1)):
+        fp = abi.make_frame_params(W, H)
+        mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0), 321 + W, 0, frames)
+        check(fp, frames, mbs, co, teams=teams, defs=defs)
 
 
 def test_emulated_fuzz():
