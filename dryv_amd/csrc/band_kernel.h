@@ -311,17 +311,14 @@ WV void idct4x4_wide(const u32x4 c0, const u32x4 c1, int lsAddr, int shl, int rn
   }
 }
 
-// largest |c| over the block's entries (entry 0 excluded when it is not a coefficient of this block)
+// largest |c| over the block's entries (entry 0 excluded when it is not a coefficient of this block); 32768 for -32768
 WV int max_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
-  const unsigned cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-  int m = 0;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    int c = (k & 1) ? ((int)cw[k >> 1] >> 16) : (int)(int16_t)cw[k >> 1];
-    if (k == 0 && skip0) c = 0;
-    m = max(m, c < 0 ? -c : c);
-  }
-  return m;
+  const unsigned w0 = skip0 ? c0.x & 0xffff0000u : c0.x;
+  // packed maxima and minima of the eight pairs, then max(hi, -lo) per half
+  const unsigned mx = wv::pk_max(wv::pk_max(wv::pk_max(w0, c0.y), wv::pk_max(c0.z, c0.w)), wv::pk_max(wv::pk_max(c1.x, c1.y), wv::pk_max(c1.z, c1.w)));
+  const unsigned mn = wv::pk_min(wv::pk_min(wv::pk_min(w0, c0.y), wv::pk_min(c0.z, c0.w)), wv::pk_min(wv::pk_min(c1.x, c1.y), wv::pk_min(c1.z, c1.w)));
+  const int hi = max((int)(int16_t)(mx & 0xffffu), (int)mx >> 16), lo = min((int)(int16_t)(mn & 0xffffu), (int)mn >> 16);
+  return max(hi, -lo);
 }
 
 // One pass of lane-per-block residuals. big = this lane's block may overflow int32. WIDE build: the whole wave then
@@ -481,17 +478,17 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       return (unsigned)(min(r0 + g, H - 1) * W + x);
     };
     auto load_desc = [&](int step) -> u32x4 {
-      const int l = wv::opaque(lane0);
+      const int l = lane0;
       return wv::ld_u128_a2(mbsF + 16u * mb_index(step, l >> 4));
     };
     auto load_kind = [&](int step) -> unsigned {
-      const int l = wv::opaque(lane0);
+      const int l = lane0;
       return *(const unsigned*)(mbsF + 16u * mb_index(step, l >> 4));
     };
     u32x4 cA0, cA1;
     int dcA;
     auto load_coefs_luma = [&](int step, unsigned d0) {
-      const int l = wv::opaque(lane0);
+      const int l = lane0;
       const int i = l & 15;
       const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);
       const int kind = (int)(d0 & 0xffu);
@@ -578,9 +575,9 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         }
         const int qm = qp - 6 * ((qp * 43) >> 8);
         residual_pass<WIDE>(cA0, cA1, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp), A.status, rA);
-        if (kind == 3) {
+        if (wv::any(kind == 3)) {  // (an unsupported record: reconstructs as zero)
 #pragma unroll
-          for (int k = 0; k < 8; k++) rA[k] = 0;
+          for (int k = 0; k < 8; k++) rA[k] = kind == 3 ? 0u : rA[k];
         }
       }
       PH(2);  // luma residuals
@@ -765,7 +762,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       return (unsigned)(min(r0 + g, H - 1) * W + x);
     };
     auto load_kind = [&](int step) -> unsigned {
-      const int l = wv::opaque(lane0);
+      const int l = lane0;
       return *(const unsigned*)(mbsF + 16u * mb_index(step + (l >> 5), (l >> 3) & 3));
     };
     u32x4 cB0, cB1;
@@ -773,7 +770,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     cB0 = cB1 = u32x4{0, 0, 0, 0};
     dcB = 0;
     auto load_coefs_chroma = [&](int step) {  // `step` even: the pair (step, step + 1)
-      const int l = wv::opaque(lane0);
+      const int l = lane0;
       const int cpl = (l >> 2) & 1, cblk = l & 3;
       const unsigned mo = mb_index(step + (l >> 5), (l >> 3) & 3) * 768u;
       const unsigned offc = 2u * (unsigned)(259 + 64 * cpl + 15 * cblk);  // one before the block's 15 AC (trans_chroma.rs:43-58)
@@ -872,9 +869,9 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
         const long long dcC = (((long long)v * ls00) * (1ll << qd)) >> 5;   // trans_chroma.rs:413
         residual_pass<WIDE>(cB0, cB1, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), A.status, rB);
-        if (kindC == 3) {
+        if (wv::any(kindC == 3)) {
 #pragma unroll
-          for (int k = 0; k < 8; k++) rB[k] = 0;
+          for (int k = 0; k < 8; k++) rB[k] = kindC == 3 ? 0u : rB[k];
         }
         load_coefs_chroma(s + 2);
         kN1 = load_kind(s + 2);
@@ -950,9 +947,12 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
             }
           }
         }
-        if (kindC == 3) {
+        if (wv::any(kindC == 3)) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
+          for (int k = 0; k < 4; k++) {
+            p01[k] = kindC == 3 ? 0u : p01[k];
+            p23[k] = kindC == 3 ? 0u : p23[k];
+          }
         }
         if (chromaLane) {
           const int st = ts + S_STC + 16 * CW * gc + 8 * CW * cpl + CW * (4 * ccy) + 8 * slotC + 4 * ccx;

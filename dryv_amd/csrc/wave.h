@@ -70,6 +70,12 @@ WV unsigned pk_add(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
 }
 WV unsigned pk_ashr5(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 5)); }
+WV unsigned pk_max(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+WV unsigned pk_min(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
 // two signed 16-bit halves -> two unsigned bytes with saturation, in bits 15:0 (v_sat_pk_u8_i16)
 WV unsigned sat_pk_u8(unsigned pair) {
   unsigned d;
@@ -232,6 +238,14 @@ WV unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
 WV unsigned sad4(unsigned w) { return (w & 0xff) + ((w >> 8) & 0xff) + ((w >> 16) & 0xff) + (w >> 24); }
 WV int med3(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
 WV int emu_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+WV unsigned pk_max(unsigned a, unsigned b) {
+  const int16_t al = (int16_t)a, ah = (int16_t)(a >> 16), bl = (int16_t)b, bh = (int16_t)(b >> 16);
+  return (unsigned)(uint16_t)(al > bl ? al : bl) | ((unsigned)(uint16_t)(ah > bh ? ah : bh) << 16);
+}
+WV unsigned pk_min(unsigned a, unsigned b) {
+  const int16_t al = (int16_t)a, ah = (int16_t)(a >> 16), bl = (int16_t)b, bh = (int16_t)(b >> 16);
+  return (unsigned)(uint16_t)(al < bl ? al : bl) | ((unsigned)(uint16_t)(ah < bh ? ah : bh) << 16);
+}
 WV unsigned pk_add_sat(unsigned a, unsigned b) {
   const int lo = emu_sat16((int)(int16_t)a + (int)(int16_t)b), hi = emu_sat16((int)(int16_t)(a >> 16) + (int)(int16_t)(b >> 16));
   return ((unsigned)lo & 0xffff) | ((unsigned)hi << 16);
