@@ -18,6 +18,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- p
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-verify > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $OUT/insts -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-verify > $OUT/insts.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/waits -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-verify > $OUT/waits.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT --kernel-trace --output-format csv -d $OUT/active -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-verify > $OUT/active.log 2>&1
 python3 - $OUT $R $WL <<'PY'
 import csv, glob, json, sys, os
 out, root, wl = sys.argv[1:4]
@@ -52,6 +53,9 @@ for name in ("fetch", "write"):
 ci, _ = counters("insts")
 cw, _ = counters("waits")
 summ["per_macroblock"] = {c: v / mbs for c, v in ci.items()}
+ca, _ = counters("active")
+# SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md, cycle constants); per macroblock
+summ["active_quad_cycles_per_macroblock"] = {c: v / mbs for c, v in ca.items()}
 summ["wave_cycle_shares"] = {c: v for c, v in cw.items()}
 fetch = summ["FETCH_SIZE_KB_per_launch_raw"] * 1024
 write = summ["WRITE_SIZE_KB_per_launch_raw"] * 1024
