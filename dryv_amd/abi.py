@@ -52,6 +52,22 @@ class MbDesc(C.Structure):
     ]
 
 
+class OutputDesc(C.Structure):
+    """dryv_output_desc (12 bytes): output format and cropping rectangle (luma samples) of the output stage."""
+    _fields_ = [("format", C.c_uint8), ("reserved", C.c_uint8 * 3), ("crop_left", C.c_uint16), ("crop_right", C.c_uint16),
+                ("crop_top", C.c_uint16), ("crop_bottom", C.c_uint16)]
+
+
+OUT_I420, OUT_NV12 = 0, 1
+
+
+def make_output_desc(fmt=OUT_I420, crop=(0, 0, 0, 0)):
+    od = OutputDesc()
+    od.format = fmt
+    od.crop_left, od.crop_right, od.crop_top, od.crop_bottom = crop
+    return od
+
+
 # numpy view of the same 16 bytes, for bulk handling
 MB_DESC_DTYPE = np.dtype([
     ("mb_kind", "u1"), ("i16_pred_mode", "u1"), ("intra_chroma_pred_mode", "u1"), ("qp", "u1"),
@@ -74,6 +90,10 @@ SYMBOLS = {
     "dryv_recon_submit_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     "dryv_recon_sync": (C.c_int, [C.c_void_p]),
+    "dryv_recon_output_bytes": (C.c_size_t, [C.POINTER(FrameParams), C.POINTER(OutputDesc)]),
+    "dryv_recon_pack_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.POINTER(OutputDesc),
+                                         C.c_void_p]),
+    "dryv_recon_wait_packed": (C.c_int, [C.c_void_p, C.POINTER(OutputDesc), C.c_void_p, C.c_size_t]),
     "dryv_recon_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "dryv_recon_stream": (C.c_void_p, [C.c_void_p]),
     "dryv_recon_strerror": (C.c_char_p, [C.c_int]),

@@ -15,6 +15,7 @@
 
 #include "recon_kernel.h"
 #include "recon_params.h"
+#include "output_pack.h"
 
 using dryv::KParams;
 using dryv::params::build_params;
@@ -30,6 +31,10 @@ struct dryv_recon_ctx {
   void* d_coeffs = nullptr;
   void* d_yuv = nullptr;
   size_t cap_mbs = 0, cap_coeffs = 0, cap_yuv = 0;
+  void* d_pack = nullptr;        // output stage (dryv_recon_wait_packed): grow-only
+  size_t cap_pack = 0;
+  dryv_frame_params pending_fp;  // the parameters of the host-path batch in flight
+  uint32_t pending_frames = 0;
   size_t pending_yuv_bytes = 0;
   bool in_flight = false;        // a submit has not been waited for
   bool in_flight_host = false;   // ... and it was a host-buffer submit
@@ -262,6 +267,7 @@ void dryv_recon_destroy(dryv_recon_ctx* ctx) {
   if (ctx->d_mbs) (void)hipFree(ctx->d_mbs);
   if (ctx->d_coeffs) (void)hipFree(ctx->d_coeffs);
   if (ctx->d_yuv) (void)hipFree(ctx->d_yuv);
+  if (ctx->d_pack) (void)hipFree(ctx->d_pack);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -296,6 +302,8 @@ int dryv_recon_submit(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t
     return fail(ctx, e, "H2D coefficients");
   if ((st = launch(ctx, P, ctx->d_mbs, ctx->d_coeffs, ctx->d_yuv)) != DRYV_OK) return st;
   ctx->pending_yuv_bytes = b_yuv;
+  ctx->pending_fp = *fp;
+  ctx->pending_frames = n_frames;
   ctx->in_flight = true;
   ctx->in_flight_host = true;
   return DRYV_OK;
@@ -319,6 +327,48 @@ int dryv_recon_wait(dryv_recon_ctx* ctx, uint8_t* yuv_out, size_t yuv_out_bytes)
   return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;
 }
 
+
+/* ---- output stage ----------------------------------------------------------------------------------- */
+size_t dryv_recon_output_bytes(const dryv_frame_params* fp, const dryv_output_desc* od) {
+  dryv::PackGeo G;
+  return dryv::pack_geometry(fp, od, 1, &G) == DRYV_OK ? G.dst_frame_bytes : 0;
+}
+
+int dryv_recon_pack_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const void* d_yuv,
+                           const dryv_output_desc* od, void* d_out) {
+  if (!ctx || !d_yuv || !d_out || n_frames == 0) return DRYV_E_INVALID;
+  if (ctx->in_flight) return DRYV_E_STATE;  // (a flagged batch is re-run at sync: its planes are final only after that)
+  dryv::PackGeo G;
+  const int st = dryv::pack_geometry(fp, od, n_frames, &G);
+  if (st != DRYV_OK) return st;
+  (void)hipSetDevice(ctx->device);
+  const hipError_t e = dryv::pack_launch(G, d_yuv, d_out, ctx->num_cus, ctx->stream);
+  return e == hipSuccess ? DRYV_OK : fail(ctx, e, "pack kernel launch");
+}
+
+int dryv_recon_wait_packed(dryv_recon_ctx* ctx, const dryv_output_desc* od, uint8_t* out, size_t out_bytes) {
+  if (!ctx || !od || !out) return DRYV_E_INVALID;
+  if (!ctx->in_flight || !ctx->in_flight_host) return DRYV_E_STATE;
+  dryv::PackGeo G;
+  int st = dryv::pack_geometry(&ctx->pending_fp, od, ctx->pending_frames, &G);
+  if (st != DRYV_OK) return st;  // (the batch stays in flight: dryv_recon_wait can still fetch it)
+  const size_t need = G.dst_frame_bytes * ctx->pending_frames;
+  if (out_bytes < need) return DRYV_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  if ((st = ensure(ctx, &ctx->d_pack, &ctx->cap_pack, need)) != DRYV_OK) return st;
+  st = finish(ctx);
+  hipError_t e = hipSuccess;
+  if (st == DRYV_OK) {
+    e = dryv::pack_launch(G, ctx->d_yuv, ctx->d_pack, ctx->num_cus, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, ctx->d_pack, need, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  ctx->in_flight = false;
+  ctx->in_flight_host = false;
+  if (st != DRYV_OK) return st;
+  if (e != hipSuccess) return fail(ctx, e, "pack / D2H");
+  return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;
+}
 
 /* ---- pinned host memory + pipelined host-buffer path ---------------------------------------------- */
 void* dryv_recon_alloc_host(size_t bytes) {

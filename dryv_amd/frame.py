@@ -89,6 +89,27 @@ class ReconContext:
         self.last_status = st
         return out
 
+    def wait_packed(self, od, allow_unsupported=False):
+        """dryv_recon_wait_packed: the batch submitted with submit(), cropped / packed on the device as `od`
+        (abi.make_output_desc) says; only those bytes are copied back."""
+        mbs, coeffs, fp = self._keep
+        per = self._lib.dryv_recon_output_bytes(C.byref(fp), C.byref(od))
+        if per == 0:
+            raise ReconError(abi.DRYV_E_INVALID, "invalid output description")
+        n_frames = mbs.size // (fp.pic_width_in_mbs * fp.pic_height_in_mbs)
+        out = np.empty(per * n_frames, dtype=np.uint8)
+        st = self._lib.dryv_recon_wait_packed(self._h, C.byref(od), out.ctypes.data, out.size)
+        self._keep = None
+        if not (allow_unsupported and st == abi.DRYV_E_UNSUPPORTED):
+            _check(st, self._h)
+        self.last_status = st
+        return out
+
+    def pack_device(self, fp, n_frames, d_yuv, od, d_out):
+        """dryv_recon_pack_device on raw device pointers; completes at sync()."""
+        _check(self._lib.dryv_recon_pack_device(self._h, C.byref(fp), int(n_frames), C.c_void_p(d_yuv), C.byref(od),
+                                                C.c_void_p(d_out)), self._h)
+
     def reconstruct(self, fp, n_frames, mbs, coeffs, allow_unsupported=False):
         self.submit(fp, n_frames, mbs, coeffs)
         return self.wait(allow_unsupported=allow_unsupported)

@@ -35,6 +35,10 @@ def _load():
         _lib.dryv_h264_info.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dryv_h264_encode_idr.restype = C.c_longlong
         _lib.dryv_h264_encode_idr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        _lib.dryv_h264_encode_idr_cropped.restype = C.c_longlong
+        _lib.dryv_h264_encode_idr_cropped.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                      C.c_size_t]
+        _lib.dryv_h264_crop.argtypes = [C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -59,14 +63,19 @@ def parse_first_islice(data):
         C.memmove(coeffs.ctypes.data, lib.dryv_h264_coeffs(h), n * 768)
         info = np.zeros(8, dtype=np.int64)
         lib.dryv_h264_info(h, info.ctypes.data)
+        crop = np.zeros(4, dtype=np.int32)
+        lib.dryv_h264_crop(h, crop.ctypes.data)
     finally:
         lib.dryv_h264_free(h)
     keys = ("bins", "slice_bytes", "bits_unread", "tail_ok", "n_i4x4", "n_i8x8", "n_i16x16", "slice_qp")
-    return fp, mbs, coeffs, dict(zip(keys, (int(v) for v in info)))
+    d = dict(zip(keys, (int(v) for v in info)))
+    d["crop"] = tuple(int(v) for v in crop)   # luma samples: left, right, top, bottom (sps.rs:252-267)
+    return fp, mbs, coeffs, d
 
 
-def encode_idr(fp, mbs, coeffs, slice_qp=26):
-    """One picture (flat scaling lists) -> Annex-B bytes (SPS, PPS, IDR I slice, CABAC)."""
+def encode_idr(fp, mbs, coeffs, slice_qp=26, crop=None):
+    """One picture (flat scaling lists) -> Annex-B bytes (SPS, PPS, IDR I slice, CABAC). crop: optional frame cropping
+    rectangle (left, right, top, bottom) in luma samples, written to the SPS."""
     lib = _load()
     mbs = np.ascontiguousarray(mbs)
     coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
@@ -74,10 +83,15 @@ def encode_idr(fp, mbs, coeffs, slice_qp=26):
     assert mbs.size == n and coeffs.size == n * 384
     cap = 64 + n * 1200
     out = np.empty(cap, dtype=np.uint8)
-    r = lib.dryv_h264_encode_idr(C.addressof(fp), mbs.ctypes.data, coeffs.ctypes.data, slice_qp, out.ctypes.data, cap)
+    cr = np.asarray(crop if crop is not None else (0, 0, 0, 0), dtype=np.int32)
+
+    def call(buf):
+        return lib.dryv_h264_encode_idr_cropped(C.addressof(fp), mbs.ctypes.data, coeffs.ctypes.data, slice_qp,
+                                                cr.ctypes.data, buf.ctypes.data, buf.size)
+    r = call(out)
     if r < 0:
         out = np.empty(-r, dtype=np.uint8)
-        r = lib.dryv_h264_encode_idr(C.addressof(fp), mbs.ctypes.data, coeffs.ctypes.data, slice_qp, out.ctypes.data, out.size)
+        r = call(out)
     if r <= 0:
         raise H264Error(lib.dryv_h264_last_error().decode())
     return out[:r].tobytes()

@@ -42,12 +42,31 @@ void dryv_h264_info(const dryv_h264_frame* h, long long* info) {
   info[7] = h->F.slice_qp;
 }
 
+/* The SPS's frame cropping rectangle in luma samples: left, right, top, bottom (0 when frame_cropping_flag is 0). */
+void dryv_h264_crop(const dryv_h264_frame* h, int* crop4) {
+  for (int k = 0; k < 4; k++) crop4[k] = h->F.crop[k];
+}
+
 /* Encodes one picture (flat scaling lists) as an Annex-B stream: SPS, PPS, one IDR I slice. Returns the byte count, or
  * 0 on failure / when `cap` is too small (call with cap = 0 to size the buffer: returns the needed size negated). */
 long long dryv_h264_encode_idr(const dryv_frame_params* fp, const dryv_mb_desc* mbs, const int16_t* coeffs, int slice_qp,
                                uint8_t* out, size_t cap) {
   try {
     const std::vector<uint8_t> v = encode_idr_annexb(*fp, mbs, coeffs, slice_qp);
+    if (v.size() > cap) return -(long long)v.size();
+    memcpy(out, v.data(), v.size());
+    return (long long)v.size();
+  } catch (const Error& e) {
+    g_err = e.what;
+    return 0;
+  }
+}
+
+/* The same with a frame cropping rectangle (luma samples: left, right, top, bottom; even) in the SPS. */
+long long dryv_h264_encode_idr_cropped(const dryv_frame_params* fp, const dryv_mb_desc* mbs, const int16_t* coeffs, int slice_qp,
+                                       const int* crop4, uint8_t* out, size_t cap) {
+  try {
+    const std::vector<uint8_t> v = encode_idr_annexb(*fp, mbs, coeffs, slice_qp, crop4);
     if (v.size() > cap) return -(long long)v.size();
     memcpy(out, v.data(), v.size());
     return (long long)v.size();

@@ -437,6 +437,9 @@ struct ParsedFrame {
   bool tail_ok = false;  // the engine stopped right behind the rbsp_stop_one_bit and only zero bits follow
   int kinds[3] = {0, 0, 0};
   int slice_qp = 0;
+  // the SPS's frame cropping rectangle in luma samples (left, right, top, bottom): sps.rs:252-267. The reference parses
+  // and ignores it; here it is handed to the caller, who may pass it on to the output stage (dryv_output_desc)
+  int crop[4] = {0, 0, 0, 0};
 };
 
 // Shared walk over the macroblock layer; CODER is CabacDecoder (fills mbs/coeffs) or CabacEncoder (reads them).
@@ -817,6 +820,7 @@ inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, 
   F.mbs.resize((size_t)W * H);
   F.coeffs.assign((size_t)W * H * 384, 0);
   F.slice_qp = h.slice_qp;
+  for (int k = 0; k < 4; k++) F.crop[k] = 2 * s.crop[k];  // CropUnitX = CropUnitY = 2 for 4:2:0 frame pictures (7.4.2.1.1)
   CabacDecoder cd;
   cd.start(&r, h.slice_qp);
   MbLayer<false, CabacDecoder> L(cd, W, H, p.transform8x8, h.slice_qp);
@@ -979,8 +983,9 @@ inline ParsedFrame parse_first_islice(const uint8_t* f, size_t n) {
 }
 
 // ---- encoder: one IDR picture as an Annex-B byte stream (SPS, PPS, one I slice) ------------------------------------------
+// crop: optional frame cropping rectangle in luma samples (left, right, top, bottom; even), written to the SPS
 inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const dryv_mb_desc* mbs, const int16_t* coeffs,
-                                              int slice_qp = 26) {
+                                              int slice_qp = 26, const int* crop = nullptr) {
   const int W = fp.pic_width_in_mbs, H = fp.pic_height_in_mbs;
   for (int l = 0; l < 6; l++) {
     for (int k = 0; k < 16; k++)
@@ -1008,7 +1013,13 @@ inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const
     w.ue((unsigned)H - 1);
     w.bit(1);  // frame_mbs_only_flag
     w.bit(1);  // direct_8x8_inference_flag
-    w.bit(0);  // frame_cropping_flag
+    const bool cropped = crop && (crop[0] | crop[1] | crop[2] | crop[3]) != 0;
+    w.bit(cropped ? 1 : 0);  // frame_cropping_flag
+    if (cropped)
+      for (int k = 0; k < 4; k++) {
+        if (crop[k] < 0 || (crop[k] & 1)) fail("encoder: crop offsets must be even and non-negative");
+        w.ue((unsigned)crop[k] / 2);
+      }
     w.bit(0);  // vui_parameters_present_flag
     w.trailing();
     append_nal_annexb(out, 0x67, w.out);

@@ -135,6 +135,28 @@ int dryv_recon_submit_device(dryv_recon_ctx *ctx, const dryv_frame_params *fp, u
                              const void *d_mbs, const void *d_coeffs, void *d_yuv_out);
 int dryv_recon_sync(dryv_recon_ctx *ctx); /* waits, then reports the batch's status word */
 
+/* ---- output stage: cropping and NV12 packing on the device ------------------------------------------
+ * The reference parses frame_crop_*_offset (sps.rs:252-267) but writes the full coded planes (frame/mod.rs:48-70;
+ * README.md:13 unchecked), which stays this library's default output. A caller that wants display-size pictures, or
+ * NV12, describes the output here; only those bytes are then produced and copied. Crop values are luma samples (twice
+ * the SPS's frame_crop_*_offset for 4:2:0 frame pictures) and must be even. */
+enum { DRYV_OUT_I420 = 0, /* Y, Cb, Cr planes (write_to_yuv_file order) */ DRYV_OUT_NV12 = 1 /* Y, interleaved CbCr */ };
+typedef struct {
+  uint8_t format; /* DRYV_OUT_* */
+  uint8_t reserved[3];
+  uint16_t crop_left, crop_right, crop_top, crop_bottom;
+} dryv_output_desc;
+/* Bytes of one output picture; 0 if the description is invalid for these parameters. */
+size_t dryv_recon_output_bytes(const dryv_frame_params *fp, const dryv_output_desc *od);
+/* Packs n_frames full planar pictures at d_yuv (as written by dryv_recon_submit_device, after dryv_recon_sync) into
+ * d_out (n_frames * dryv_recon_output_bytes()). Asynchronous on the context's stream; pair with dryv_recon_sync.
+ * DRYV_E_STATE while a batch is in flight. */
+int dryv_recon_pack_device(dryv_recon_ctx *ctx, const dryv_frame_params *fp, uint32_t n_frames, const void *d_yuv,
+                           const dryv_output_desc *od, void *d_out);
+/* dryv_recon_wait with an output description: blocks until the batch submitted with dryv_recon_submit is done, packs
+ * it on the device and copies n_frames * dryv_recon_output_bytes() bytes into out. */
+int dryv_recon_wait_packed(dryv_recon_ctx *ctx, const dryv_output_desc *od, uint8_t *out, size_t out_bytes);
+
 /* Device time of the most recent reconstruction kernel launch, from HIP events recorded on the
  * context's own stream immediately around the launch. Valid after wait/sync. */
 int dryv_recon_last_kernel_ms(dryv_recon_ctx *ctx, float *ms);

@@ -120,3 +120,21 @@ def test_parameter_bounds_are_checked_without_a_device():
     bad = abi.make_frame_params(4, 4)
     bad.bit_depth_y = 10
     assert lib.dryv_recon_check_params(bad, 1) == abi.DRYV_E_UNSUPPORTED
+
+
+def test_output_stage_geometry_and_validation():
+    """dryv_recon_output_bytes (pure host code): display size after cropping, both formats the same byte count, odd or
+    oversized crops and unknown formats rejected (0)."""
+    lib = abi.load_library()
+    fp = abi.make_frame_params(120, 68)                       # 1920 x 1088 coded
+    full = lib.dryv_recon_output_bytes(C.byref(fp), C.byref(abi.make_output_desc()))
+    assert full == 1920 * 1088 * 3 // 2 == lib.dryv_recon_frame_bytes(C.byref(fp))
+    od = abi.make_output_desc(abi.OUT_NV12, (0, 0, 0, 8))     # 1080p: frame_crop_bottom_offset = 4 units
+    assert lib.dryv_recon_output_bytes(C.byref(fp), C.byref(od)) == 1920 * 1080 * 3 // 2
+    od = abi.make_output_desc(abi.OUT_I420, (2, 6, 4, 10))
+    assert lib.dryv_recon_output_bytes(C.byref(fp), C.byref(od)) == (1920 - 8) * (1088 - 14) * 3 // 2
+    for bad in (abi.make_output_desc(abi.OUT_I420, (1, 0, 0, 0)), abi.make_output_desc(abi.OUT_I420, (0, 0, 0, 3)),
+                abi.make_output_desc(abi.OUT_I420, (960, 960, 0, 0)), abi.make_output_desc(abi.OUT_I420, (0, 0, 1000, 88)),
+                abi.make_output_desc(7, (0, 0, 0, 0))):
+        assert lib.dryv_recon_output_bytes(C.byref(fp), C.byref(bad)) == 0
+    assert C.sizeof(abi.OutputDesc) == 12

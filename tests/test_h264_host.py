@@ -102,3 +102,18 @@ def test_real_stream_survives_reencoding():
     st1, y1 = oracle.reconstruct(fp, 1, mbs, co)
     st2, y2 = oracle.reconstruct(fp2, 1, mbs2, co2)
     assert np.array_equal(y1, y2)
+
+
+def test_frame_cropping_rectangle_round_trips():
+    """The SPS's frame cropping rectangle (sps.rs:252-267: parsed by the reference, never applied) comes out of the parser
+    in luma samples, as the output stage takes it; the encoder writes it. realshort.mp4 (320x240 = 20x15 macroblocks)
+    has none."""
+    assert h264.parse_first_islice(open(FIXTURE, "rb").read())[3]["crop"] == (0, 0, 0, 0)
+    fp = abi.make_frame_params(8, 5)                          # 128 x 80 coded
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0), 4242, 0, 1)
+    stream = h264.encode_idr(fp, mbs, co, slice_qp=int(mbs["qp"][0]), crop=(2, 6, 0, 8))   # a 120 x 72 picture
+    fp2, mbs2, co2, info = h264.parse_first_islice(stream)
+    assert info["crop"] == (2, 6, 0, 8) and info["tail_ok"] == 1
+    assert np.array_equal(co2, co)
+    with pytest.raises(h264.H264Error):
+        h264.encode_idr(fp, mbs, co, crop=(1, 0, 0, 0))      # odd: not expressible in crop units

@@ -416,3 +416,59 @@ def test_pipelined_host_path_chunk_boundaries(recon_ctx):
         os.environ.pop("DRYV_RECON_CHUNK_FRAMES", None)
         for a in (pm, pc, po):
             recon_ctx.free_host(a)
+
+
+def _expected_packed(yuv, W, H, frames, fmt, crop):
+    """The output stage restated in numpy: crop the oracle's full planes, then I420 or NV12 byte order."""
+    l, r, t, b = crop
+    out = []
+    per = W * H * 384
+    for f in range(frames):
+        Y, Cb, Cr = split_planes(yuv[f * per:(f + 1) * per], W, H)
+        Y = Y[t:16 * H - b, l:16 * W - r]
+        Cb = Cb[t // 2:8 * H - b // 2, l // 2:8 * W - r // 2]
+        Cr = Cr[t // 2:8 * H - b // 2, l // 2:8 * W - r // 2]
+        out.append(Y.reshape(-1))
+        if fmt == abi.OUT_NV12:
+            out.append(np.stack([Cb, Cr], axis=-1).reshape(-1))
+        else:
+            out += [Cb.reshape(-1), Cr.reshape(-1)]
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("geo", [(7, 5, 2, (0, 0, 0, 0)), (7, 5, 2, (2, 6, 4, 10)), (12, 9, 1, (0, 0, 0, 8)),
+                                 (3, 2, 3, (14, 16, 2, 0)), (1, 1, 1, (0, 2, 0, 2)), (20, 4, 1, (6, 0, 30, 0))])
+def test_output_stage_crop_and_nv12(recon_ctx, geo):
+    """cropping and NV12 packing on the device. The reference has no such stage (it parses the SPS's
+    cropping rectangle and ignores it), so the expectation is the stage's definition applied to the oracle's planes:
+    rows / columns sliced, chroma at half the offsets, NV12 = Cb and Cr interleaved. Through both entry points."""
+    import torch
+    W, H, frames, crop = geo
+    fp = abi.make_frame_params(W, H)
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0), 777 + W, 0, frames)
+    st, full = oracle.reconstruct(fp, frames, mbs, co)
+    assert st == 0
+    for fmt in (abi.OUT_I420, abi.OUT_NV12):
+        od = abi.make_output_desc(fmt, crop)
+        want = _expected_packed(full, W, H, frames, fmt, crop)
+        recon_ctx.submit(fp, frames, mbs, co)
+        got = recon_ctx.wait_packed(od)
+        assert got.size == want.size and np.array_equal(got, want), (fmt, int(np.flatnonzero(got != want)[0]))
+        # device-resident: reconstruct, sync, pack, sync
+        d_m = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda()
+        d_c = torch.from_numpy(co).cuda()
+        d_y = torch.zeros(full.size, dtype=torch.uint8, device="cuda")
+        d_o = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+        recon_ctx.submit_device(fp, frames, d_m.data_ptr(), d_c.data_ptr(), d_y.data_ptr())
+        with pytest.raises(ReconError):                       # not while the batch is in flight
+            recon_ctx.pack_device(fp, frames, d_y.data_ptr(), od, d_o.data_ptr())
+        recon_ctx.sync()
+        recon_ctx.pack_device(fp, frames, d_y.data_ptr(), od, d_o.data_ptr())
+        recon_ctx.sync()
+        assert np.array_equal(d_o.cpu().numpy(), want)
+    # an invalid description leaves the batch in flight for a plain wait
+    recon_ctx.submit(fp, frames, mbs, co)
+    with pytest.raises(ReconError):
+        recon_ctx.wait_packed(abi.make_output_desc(abi.OUT_I420, (0, 0, 16 * H, 0)))
+    recon_ctx._keep = (mbs, co, fp)
+    assert np.array_equal(recon_ctx.wait(), full)
