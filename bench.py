@@ -188,7 +188,8 @@ def main():
         all_verified, kernel_ms_max = verified, float(vt[1].item())
     if not all_verified:
         sys.exit("bench.py: a rank's shard differs from the oracle")
-    kernel_name = "band_kernel" if (not t8 and os.environ.get("DRYV_RECON_KERNEL", "") != "row") else "recon_kernel"
+    sel = os.environ.get("DRYV_RECON_KERNEL", "")   # default: band kernel, except streams with the 8x8 transform
+    kernel_name = "band_kernel" if (sel == "band" or (sel != "row" and not t8)) else "recon_kernel"
 
     if rank == 0:
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3

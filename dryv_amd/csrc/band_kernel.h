@@ -56,8 +56,10 @@ constexpr int T_THR4 = 304;   // u16 [52]
 constexpr int T_THR8 = 408;   // u16 [52]
 constexpr int T_T4E = 512;    // u32 [12][8][2] Intra4x4 entries [mode][pixel pair][pixel]
 constexpr int T_END = 1280;
-constexpr int T_LS8 = 1280;   // u16 [6][64]    (HAS_I8 only)
-constexpr int T_END_I8 = 2048;
+constexpr int T_LS8 = 1280;   // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
+constexpr int T_T8 = 2048;    // u8  [9][64]    Intra8x8 table [mode][y*8+x]: index on the filtered edge | value kind << 5
+constexpr int T_ZZ8 = 2624;   // u8  [64]       8x8 list index -> 2 * raster position
+constexpr int T_END_I8 = 2688;
 
 // ---- per-team scratch in LDS (byte offsets from the team's base) ---------------------------------------------
 // Output staging: a row's pixels are flushed to global memory NSY (luma) / NSC (chroma) macroblocks at a time, as
@@ -94,6 +96,13 @@ constexpr int S_LEFTC = S_RINGC + 256;            // u8 [4][2][8]
 // FRONT
 constexpr int S_RINGM = S_LEFTC + 64;             // u32 [4][4]  bottom-row modes of the row above
 constexpr int S_BYTES = (S_RINGM + 64 + 63) & ~63;
+// builds that serve the 8x8 transform (HAS_I8) append, per team:
+constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order
+constexpr int S_G8 = S_C8 + 2048;      // T   [4][2 blk8][8][8]  FRONT: row-pass output of the two blocks of a pass (T up to 8 bytes)
+constexpr int S_E8 = S_G8 + 4096;      // [4][128]  BACK: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16,
+                                       //           then E1 as bytes (L7..L0, TL at 100..108, T0..T15 at 112..127)
+constexpr int S_BYTES_I8 = S_E8 + 512;
+constexpr int team_bytes(bool hasI8) { return hasI8 ? S_BYTES_I8 : S_BYTES; }
 static_assert(S_RINGM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
@@ -214,8 +223,11 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
     }
     wv::lds_st32(ldsBase + T_T4E + 4 * k, v);
   }
-  if (hasI8)
+  if (hasI8) {
     for (int k = tid; k < 384; k += nthreads) wv::lds_st16(ldsBase + T_LS8 + 2 * k, P.ls8[k]);
+    for (int k = tid; k < 576; k += nthreads) wv::lds_st8(ldsBase + T_T8 + k, P.t8[k]);
+    for (int k = tid; k < 64; k += nthreads) wv::lds_st8(ldsBase + T_ZZ8 + P.zz8i[k], (unsigned)(2 * k));
+  }
 }
 
 // ---- 4x4 residual of one block, all in this lane (transform.rs:116-191, 8.5.12) --------------------------------
@@ -343,6 +355,113 @@ WV void residual_pass(const u32x4 c0, const u32x4 c1, int lsAddr, int qp, bool u
   }
   const u32x4 l0 = wv::lds_u128(lsAddr), l1 = wv::lds_u128(lsAddr + 16);
   idct4x4<int>(c0, c1, l0, l1, shl, rnd, shr, useDc, (int)dcVal, out);
+}
+
+// ---- 8x8 residuals of the step's Intra8x8 macroblocks (8.5.13, pred8x8.rs:51-150) ----------------------------------
+// 8-point butterfly shared by the row and the column pass (pred8x8.rs:85-141)
+template <typename T>
+WV void idct8(const T d[8], T o[8]) {
+  const T e0 = d[0] + d[4];
+  const T e1 = -d[3] + d[5] - d[7] - (d[7] >> 1);
+  const T e2 = d[0] - d[4];
+  const T e3 = d[1] + d[7] - d[3] - (d[3] >> 1);
+  const T e4 = (d[2] >> 1) - d[6];
+  const T e5 = -d[1] + d[7] + d[5] + (d[5] >> 1);
+  const T e6 = d[2] + (d[6] >> 1);
+  const T e7 = d[3] + d[5] + d[1] + (d[1] >> 1);
+  const T f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+  const T f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+  o[0] = f0 + f7;
+  o[1] = f2 + f5;
+  o[2] = f4 + f3;
+  o[3] = f6 + f1;
+  o[4] = f6 - f1;
+  o[5] = f4 - f3;
+  o[6] = f2 - f5;
+  o[7] = f0 - f7;
+}
+
+// Two passes over the macroblock's four 8x8 blocks, two blocks per pass; the 16 lanes of a macroblock are (block, row),
+// then (block, column), with the row-pass output transposed through LDS. In: the coefficients already in raster order
+// in S_C8. Out: out[4 * pass + m] = rows 2m, 2m+1 of this lane's column as a saturated int16 pair.
+template <typename T>
+WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts, unsigned out[8]) {
+  const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
+  // qp >= 36: (c * LS) << (qp/6 - 6), else (c * LS + 2^(5 - qp/6)) >> (6 - qp/6)   (pred8x8.rs:73-78)
+  const int shl = max(qd - 6, 0), shr = max(6 - qd, 0), rnd = qd < 6 ? (1 << (5 - qd)) : 0;
+  const int g8 = ts + S_G8 + (int)sizeof(T) * (128 * g + 64 * (i >> 3));
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int b8 = 2 * p + (i >> 3), r = i & 7;
+    T dd[8], oo[8];
+    if (mine) {
+      const u32x4 cr = wv::lds_u128(ts + S_C8 + 512 * g + 128 * b8 + 16 * r);
+      const u32x4 lr = wv::lds_u128(ldsBase + T_LS8 + 128 * qm + 16 * r);
+      const unsigned cw[4] = {cr.x, cr.y, cr.z, cr.w}, lw[4] = {lr.x, lr.y, lr.z, lr.w};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int c = (j & 1) ? ((int)cw[j >> 1] >> 16) : (int)(int16_t)cw[j >> 1];
+        const int l = (j & 1) ? (int)(lw[j >> 1] >> 16) : (int)(lw[j >> 1] & 0xffffu);
+        dd[j] = ((((T)(c * l)) * ((T)1 << shl)) + (T)rnd) >> shr;   // |c * l| <= 2^15 * 255 * 58 fits int32
+      }
+      idct8<T>(dd, oo);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (sizeof(T) == 4) wv::lds_st32(g8 + 4 * (8 * r + j), (unsigned)oo[j]);
+        else wv::lds_st64(g8 + 8 * (8 * r + j), u32x2{(unsigned)(unsigned long long)oo[j], (unsigned)((unsigned long long)oo[j] >> 32)});
+      }
+    }
+    wv::wave_sync();
+    if (mine) {
+      const int j = i & 7;  // this lane now owns column j of its block
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (sizeof(T) == 4) dd[k] = (T)(int)wv::lds_u32(g8 + 4 * (8 * k + j));
+        else {
+          const u32x2 v = wv::lds_u64(g8 + 8 * (8 * k + j));
+          dd[k] = (T)(long long)(((unsigned long long)v.y << 32) | v.x);
+        }
+      }
+      idct8<T>(dd, oo);
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const T lo = (T)-32768, hi = (T)32767;
+        const int a = (int)min(max((oo[2 * m] + 32) >> 6, lo), hi), b = (int)min(max((oo[2 * m + 1] + 32) >> 6, lo), hi);
+        out[4 * p + m] = ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+      }
+    }
+    wv::wave_sync();  // (S_G8 is reused by the next pass)
+  }
+}
+
+// c0/c1: the 16 list entries this lane loaded: entries 16 * (i & 3) .. +15 of 8x8 block i >> 2. mine: this lane's macroblock
+// is a valid Intra8x8 one. Overflow handling as in residual_pass (thr8: |d| <= 2^23 keeps both 8-point passes in int32).
+template <bool WIDE>
+WV void residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp, int ldsBase, int ts, unsigned* status,
+                    unsigned out[8]) {
+  const int g = lane >> 4, i = lane & 15;
+  const int thr = (int)wv::lds_u16(ldsBase + T_THR8 + 2 * qp);
+  bool big = false;
+  if (wv::any(mine && thr != 0xFFFF)) big = mine && thr != 0xFFFF && max_abs16(c0, c1, false) > thr;
+  // list order -> raster (frame/mod.rs:212-284): one 16-bit store per entry
+  if (mine) {
+    const int dst = ts + S_C8 + 512 * g + 128 * (i >> 2);
+    const u32x4 zp = wv::lds_u128(ldsBase + T_ZZ8 + 16 * (i & 3));
+    const unsigned zw[4] = {zp.x, zp.y, zp.z, zp.w}, cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      wv::lds_st16(dst + (int)((zw[k >> 2] >> (8 * (k & 3))) & 0xffu), (k & 1) ? cw[k >> 1] >> 16 : cw[k >> 1]);
+  }
+  wv::wave_sync();
+  if (WIDE) {
+    if (wv::any(big)) {
+      residual8x8_passes<long long>(mine, g, i, qp, ldsBase, ts, out);
+      return;
+    }
+  } else if (big) {
+    wv::atomic_or(status, 2u);
+  }
+  residual8x8_passes<int>(mine, g, i, qp, ldsBase, ts, out);
 }
 
 // lane i ^ 4 and i ^ 8 inside a 16-lane DPP row
@@ -574,7 +693,16 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           dcY = qd >= 6 ? prod * (1ll << (qd - 6)) : (prod + (1ll << (5 - qd))) >> (6 - qd);
         }
         const int qm = qp - 6 * ((qp * 43) >> 8);
-        residual_pass<WIDE>(cA0, cA1, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp), A.status, rA);
+        // (an Intra8x8 lane's result of this pass is not used: it must not raise the 4x4 overflow flag either)
+        const int thr4 = (HAS_I8 && kind == 1) ? 0xFFFF : (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp);
+        residual_pass<WIDE>(cA0, cA1, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, thr4, A.status, rA);
+        // Intra8x8 macroblocks: their lanes' rA becomes 16 residuals of one column per 8x8 block pass (residual8x8)
+        if (HAS_I8 && wv::any(valid && kind == 1)) {
+          unsigned r8[8];
+          residual8x8<WIDE>(cA0, cA1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, r8);
+#pragma unroll
+          for (int k = 0; k < 8; k++) rA[k] = kind == 1 ? r8[k] : rA[k];
+        }
         if (wv::any(kind == 3)) {  // (an unsupported record: reconstructs as zero)
 #pragma unroll
           for (int k = 0; k < 8; k++) rA[k] = kind == 3 ? 0u : rA[k];
@@ -627,8 +755,21 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       // ---- the step's record for BACK: residuals [blkIdx][y][x], table rows, kinds. The buffer is free once BACK has
       // finished the step two back.
       if (gstep >= 2) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - 1);
-      wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
-      wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
+      if (HAS_I8 && kind == 1) {
+        // this lane holds column j = i & 7 of 8x8 blocks i >> 3 (rA[0..3]) and 2 + (i >> 3) (rA[4..7]), rows 2m, 2m+1 per
+        // word: element (row k, column j) goes to 4x4 block 4 * b8 + 2 * (k >> 2) + (j >> 2), position (k & 3, j & 3)
+        const int j = i & 7;
+        const int dst = ts + S_RES + 2048 * buf + 512 * g + 128 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
+#pragma unroll
+        for (int pk = 0; pk < 16; pk++) {
+          const int p = pk >> 3, k = pk & 7;
+          const unsigned w = rA[4 * p + (k >> 1)];
+          wv::lds_st16(dst + 256 * p + 64 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
+        }
+      } else {
+        wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
+        wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
+      }
       if (i == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 4 * g, (unsigned)kind | ((unsigned)i16mode << 8));
       if (lane == 0) {
         wv::lds_st32(ts + S_INFO + 32 * buf + 16, task);
@@ -647,9 +788,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       // mode grid = raster block grid, one DPP row per macroblock. Relaxation: after sweep k every block with
       // bx + by <= k is final.
       int Mcur = 2;
-      const bool anyI4 = wv::any(valid && kind == 0);
+      // Intra8x8 (8.3.2.1, pred8x8.rs:698-764): each 8x8 block fills its four grid positions with its mode; the block's
+      // top-left position derives it exactly like a 4x4 block there would (its A is the position left of the block's
+      // first row, its B the one above its first column), the other three copy it after every sweep.
+      const bool anyI4 = wv::any(valid && (kind == 0 || (HAS_I8 && kind == 1)));
       if (anyI4) {
-        const int mzb = zidx(rbx, rby);
+        const bool is8 = HAS_I8 && kind == 1;
+        const int mzb = is8 ? 2 * (rby >> 1) + (rbx >> 1) : zidx(rbx, rby);
         const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
         const bool prev = ((prevFlags >> mzb) & 1u) != 0;
         const unsigned upM = mbB ? wv::lds_u32(ts + S_RINGM + 16 * g + 4 * (x & 3)) : 0x02020202u;
@@ -664,6 +809,11 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           const int Bm = wv::dpp<DPP_ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
           const int pm = unav ? 2 : min(Am, Bm);
           M = prev ? pm : (rem < pm ? rem : rem + 1);
+          if (HAS_I8) {
+            const int t = wv::dppx<DPP_QUAD(0, 0, 2, 2)>(M);        // the even column's value
+            const int u = wv::dpp<DPP_ROW_SHR(4)>(t, t);            // ... of the grid row above
+            if (is8) M = (rby & 1) ? u : t;
+          }
         }
         int Mp = M;
         {
@@ -681,6 +831,9 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           const int t = rbx + 2 * rby;
           const int hh = rby != stepByLo(t) ? 1 : 0;
           wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + 12 * hh + t, (unsigned)Mp);
+        } else if (is8) {
+          Mcur = M;
+          if (((rbx | rby) & 1) == 0) wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + mzb, (unsigned)M);  // BACK: modes of blocks 0..3
         }
       }
 
@@ -1246,6 +1399,86 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         I4_STEP(0) I4_STEP(1) I4_STEP(2) I4_STEP(3) I4_STEP(4) I4_STEP(5) I4_STEP(6) I4_STEP(7) I4_STEP(8) I4_STEP(9)
 #undef I4_BLK
 #undef I4_STEP
+      }
+
+      // ================= luma, Intra8x8 (8.3.2, pred8x8.rs:152-696): four serial blocks ============================
+      // The 16 lanes of a macroblock first build the block's filtered edge E1[0..24] = L7..L0, TL, T0..T15 (8.3.2.2.1,
+      // pred8x8.rs:222-288, incl. quirk Q1), two samples per lane with the neighbours exchanged by DPP, together with the
+      // 3-tap F and 2-tap G of the filtered samples; then every lane predicts four pixels of one row from the per-(mode,
+      // pixel) table (index on the edge, which of E1 / F / G), adds the residual and stores them into the tile.
+      if (HAS_I8 && wv::any(valid && kind == 1)) {
+        const bool mine = valid && kind == 1;
+        const int e8 = ts + S_E8 + 128 * g;
+        const unsigned modes4 = wv::lds_u32(ts + S_MSEQ + 96 * buf + 24 * g);
+        const bool mbC = mbB && (x + 1 < P.W);
+        const int py = i >> 1, x0 = 4 * (i & 1);
+#pragma unroll
+        for (int b8 = 0; b8 < 4; b8++) {
+          const int bx = b8 & 1, by = b8 >> 1;
+          const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA, tlAv = topAv && leftAv;
+          const bool trAv = b8 == 0 ? mbB : b8 == 1 ? mbC : b8 == 2;
+          const int mode = min((int)((modes4 >> (8 * b8)) & 0xffu), 8);
+          const int org8 = tile + TILE_STRIDE * (8 * by) + 8 + 16 * slot + 8 * bx;  // row y = -1, x = 0 of the block
+          // raw edge samples k = i and k = i + 16 (top-right replaced by T7 when unavailable)
+          auto eaddr = [&](int k) -> int {
+            const int ei = min(k, trAv ? 24 : 16);
+            return ei <= 7 ? org8 + TILE_STRIDE * (8 - ei) - 1 : ei == 8 ? org8 - 1 : org8 + ei - 9;
+          };
+          const int lo = (int)wv::lds_u8(eaddr(i)), hi = (int)wv::lds_u8(eaddr(min(i + 16, 24)));
+          // neighbours along the edge: lane 15's right neighbour is lane 0's second sample and vice versa
+          int lfLo = wv::dpp<DPP_ROW_SHR(1)>(lo, lo);                               // (k = 0 keeps itself)
+          int rtLo = wv::dpp<DPP_ROW_SHL(1)>(wv::dppx<DPP_ROW_ROR(15)>(hi), lo);
+          int lfHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(lo), hi);
+          int rtHi = wv::dpp<DPP_ROW_SHL(1)>(hi, hi);
+          if (i >= 8) rtHi = hi;                                                    // k >= 24: no right neighbour
+          if (i == 8) {                                                             // the corner
+            if (!leftAv) lfLo = lo;
+            if (!topAv) rtLo = lo;
+          }
+          if (i == 9 && !tlAv) lfLo = -1;  // Q1: p[-1,-1] = -1 enters the x = 0 filter tap
+          if (i == 7 && !tlAv) rtLo = lo;
+          const int e1Lo = (lfLo + 2 * lo + rtLo + 2) >> 2, e1Hi = (lfHi + 2 * hi + rtHi + 2) >> 2;
+          const int elLo = wv::dpp<DPP_ROW_SHR(1)>(e1Lo, e1Lo);
+          const int erLo = wv::dpp<DPP_ROW_SHL(1)>(wv::dppx<DPP_ROW_ROR(15)>(e1Hi), e1Lo);
+          const int elHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(e1Lo), e1Hi);
+          int erHi = wv::dpp<DPP_ROW_SHL(1)>(e1Hi, e1Hi);
+          if (i >= 8) erHi = e1Hi;
+          const unsigned pkLo = ((unsigned)e1Lo & 0xffu) | ((((unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2) & 0xffu) << 8) |
+                                ((((unsigned)(e1Lo + erLo + 1) >> 1) & 0xffu) << 16);
+          const unsigned pkHi = ((unsigned)e1Hi & 0xffu) | ((((unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2) & 0xffu) << 8) |
+                                ((((unsigned)(e1Hi + erHi + 1) >> 1) & 0xffu) << 16);
+          wv::lds_st32(e8 + 4 * i, pkLo);
+          wv::lds_st8(e8 + 100 + (i <= 8 ? i : i + 3), (unsigned)e1Lo);
+          if (i <= 8) {
+            wv::lds_st32(e8 + 4 * (i + 16), pkHi);
+            wv::lds_st8(e8 + 100 + i + 19, (unsigned)e1Hi);
+          }
+          wv::wave_sync();
+          // four pixels of row py: x0 .. x0 + 3
+          const unsigned te4 = wv::lds_u32(ldsBase + T_T8 + 64 * mode + 8 * py + x0);
+          unsigned pr[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const unsigned te = (te4 >> (8 * q)) & 0xffu;
+            const unsigned w = wv::lds_u32(e8 + 4 * (int)(te & 31u));
+            pr[q] = (w >> (8 * (te >> 5))) & 0xffu;
+          }
+          {
+            const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | (tlAv ? 4 : 0);
+            const int req = (int)((0x217771021ull >> (4 * mode)) & 7ull);
+            if ((req & ~have) != 0) pr[0] = pr[1] = pr[2] = pr[3] = 0;   // quirk Q4
+            if (mode == 2) {  // DC (pred8x8.rs:350-394)
+              const int sumL = (int)wv::sad4(wv::lds_u32(e8 + 100)) + (int)wv::sad4(wv::lds_u32(e8 + 104));
+              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 112)) + (int)wv::sad4(wv::lds_u32(e8 + 116));
+              const int dc = (topAv && leftAv) ? (sumT + sumL + 8) >> 4 : leftAv ? (sumL + 4) >> 3 : topAv ? (sumT + 4) >> 3 : 128;
+              pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
+            }
+          }
+          const u32x2 rr = wv::lds_u64(resBuf + 512 * g + 32 * (4 * b8 + 2 * (py >> 2) + (x0 >> 2)) + 8 * (py & 3));
+          const unsigned o = recon_row(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16), rr.x, rr.y);
+          if (mine) wv::lds_st32(org8 + TILE_STRIDE * (py + 1) + x0, o);
+          wv::wave_sync();
+        }
       }
 
       // the record has been consumed

@@ -95,7 +95,7 @@ size_t workspace_bytes(const KParams& P) {
 int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, bool wide) {
   hipError_t e;
   const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
-  const int wpb = dryv::band_teams_per_block();
+  const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, wide);
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
   if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
   if (grid < 1) grid = 1;
@@ -126,7 +126,7 @@ int launch_chunk(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const
   ctx->last_band = band;
   if (band) {
     const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
-    const int wpb = dryv::band_teams_per_block();
+    const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, false);
     long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
     grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
     if ((e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
@@ -150,9 +150,11 @@ int finish(dryv_recon_ctx* ctx) {
   if (ctx->piped) {
     ctx->piped = false;
     if ((e = hipStreamSynchronize(ctx->s_out)) != hipSuccess) return fail(ctx, e, "hipStreamSynchronize(copy-out)");
-    if (ctx->last_band && (*ctx->h_status & 2u)) {
-      // a block beyond int32: the whole batch again, unpipelined, with the wide build (never for a conformant stream)
+    if (*ctx->h_status & 2u) {
+      // a block beyond int32 (flagged by either kernel): the whole batch again, unpipelined, with the band kernel's wide
+      // build (never for a conformant stream)
       ctx->wide_reruns++;
+      ctx->last_band = true;
       const KParams& P = ctx->last_P;
       if ((e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
       int st = launch_band(ctx, P, ctx->d_mbs, ctx->d_coeffs, ctx->d_yuv, true);
@@ -162,8 +164,9 @@ int finish(dryv_recon_ctx* ctx) {
       if (e != hipSuccess) return fail(ctx, e, "wide re-run");
     }
   } else
-  if (ctx->last_band && (*ctx->h_status & 2u)) {
+  if (*ctx->h_status & 2u) {
     ctx->wide_reruns++;
+    ctx->last_band = true;
     e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
     if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
     int st = launch_band(ctx, ctx->last_P, ctx->last_mbs, ctx->last_coeffs, ctx->last_yuv, true);

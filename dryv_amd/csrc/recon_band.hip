@@ -6,8 +6,9 @@
 
 namespace dryv {
 
-// A workgroup = TEAMS_PER_WG teams of a FRONT, a BACK and a CHROMA wave. The fast build needs 56 VGPRs (8 waves per SIMD
-// fit); the wide build (64-bit residual arithmetic, re-run of a flagged batch only) is compiled for 5 waves per SIMD.
+// A workgroup = TEAMS_PER_WG teams of a FRONT, a BACK and a CHROMA wave. The fast build for streams without the 8x8
+// transform needs 68 VGPRs; the one with it is compiled for 5 waves per SIMD (96 VGPRs), the wide builds (64-bit residual
+// arithmetic, re-run of a flagged batch only) for 4.
 // Grid shape: tools/band_variants.sh (measurements in DESIGN.md).
 #ifndef DRYV_BAND_WPS
 #define DRYV_BAND_WPS 6   // waves per SIMD the fast build is compiled for (<= 80 VGPRs)
@@ -16,26 +17,27 @@ namespace dryv {
 #define DRYV_BAND_WGS_PER_CU 2
 #endif
 template <bool HAS_I8, bool WIDE>
-__global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 5 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
+__global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds[];
   const int ldsBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   constexpr int tEnd = HAS_I8 ? band::T_END_I8 : band::T_END;
   A.waveBase = (int)blockIdx.x * band::WAVES_PER_WG;
   band::build_tables(P, ldsBase, (int)threadIdx.x, (int)blockDim.x, HAS_I8);
-  if (threadIdx.x < 16 * band::TEAMS_PER_WG)  // the teams' flag words
-    wv::lds_st32(ldsBase + tEnd + (int)(threadIdx.x >> 4) * band::S_BYTES + band::S_FLAGS + 4 * (int)(threadIdx.x & 15), 0u);
+  if (threadIdx.x < 16 * (blockDim.x / (64 * band::WAVES_PER_TEAM)))  // the teams' flag words
+    wv::lds_st32(ldsBase + tEnd + (int)(threadIdx.x >> 4) * band::team_bytes(HAS_I8) + band::S_FLAGS + 4 * (int)(threadIdx.x & 15), 0u);
   __syncthreads();  // the only workgroup-level synchronisation: the teams are independent from here on
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // consecutive waves of a workgroup go to different SIMDs: a team's three waves never share one
   const int team = wave / band::WAVES_PER_TEAM, role = wave - team * band::WAVES_PER_TEAM;
-  const int ts = ldsBase + tEnd + team * band::S_BYTES;
+  const int ts = ldsBase + tEnd + team * band::team_bytes(HAS_I8);
   if (role == 1) band::band_back<HAS_I8>(P, A, ldsBase, ts);
   else if (role == 0) band::band_front<HAS_I8, WIDE>(P, A, ldsBase, ts);
   else band::band_chroma<HAS_I8, WIDE>(P, A, ldsBase, ts);
 }
 
-size_t band_lds_bytes(bool hasI8) { return (size_t)(hasI8 ? band::T_END_I8 : band::T_END) + (size_t)band::TEAMS_PER_WG * band::S_BYTES; }
-int band_teams_per_block() { return band::TEAMS_PER_WG; }
+size_t band_lds_bytes(bool hasI8, int teams) { return (size_t)(hasI8 ? band::T_END_I8 : band::T_END) + (size_t)teams * band::team_bytes(hasI8); }
+// The builds that need more registers (8x8 transform: 96 VGPRs; wide: up to 128) run three teams per workgroup at most.
+int band_teams_per_block(bool hasI8, bool wide) { return (hasI8 || wide) ? (band::TEAMS_PER_WG < 3 ? band::TEAMS_PER_WG : 3) : band::TEAMS_PER_WG; }
 int band_blocks_per_cu() { return DRYV_BAND_WGS_PER_CU; }
 
 // Workspace: [task counter | pad to 256][luma | chroma | modes progress words | pad to 256][bottom-row modes]
@@ -68,8 +70,9 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   A.profile = (unsigned long long*)(wsb + band_profile_offset(P));
 #endif
   const bool i8 = P.transform8x8 != 0;
-  const size_t ldsBytes = band_lds_bytes(i8);
-  const dim3 g(grid), b(64 * band::WAVES_PER_WG);
+  const int teams = band_teams_per_block(i8, wide);
+  const size_t ldsBytes = band_lds_bytes(i8, teams);
+  const dim3 g(grid), b(64 * band::WAVES_PER_TEAM * teams);
   if (ldsBytes > 65536) {  // (build variants with wide staging: beyond the default dynamic LDS limit)
     const void* fn = i8 ? (wide ? (const void*)band_kernel<true, true> : (const void*)band_kernel<true, false>)
                         : (wide ? (const void*)band_kernel<false, true> : (const void*)band_kernel<false, false>);

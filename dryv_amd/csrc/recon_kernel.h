@@ -20,9 +20,9 @@ int recon_blocks_per_cu();
 hipError_t recon_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv,
                         unsigned* d_status, void* d_workspace, int grid, hipStream_t stream);
 
-// Band kernel (band_kernel.h): a team of two waves per 4-row band; grid = workgroups of band_teams_per_block() teams.
-size_t band_lds_bytes(bool hasI8);
-int band_teams_per_block();
+// Band kernel (band_kernel.h): a team of three waves per 4-row band; grid = workgroups of band_teams_per_block() teams.
+size_t band_lds_bytes(bool hasI8, int teams);
+int band_teams_per_block(bool hasI8, bool wide);
 int band_blocks_per_cu();
 size_t band_workspace_bytes(const KParams& P);
 size_t band_reset_bytes(const KParams& P);      // leading bytes of the workspace a launch needs zeroed

@@ -463,7 +463,8 @@ struct BandShared {
 #define LT_T4E 4320     // u32 [12][16]  Intra4x4 prediction entries [mode][x][y] (9: zero, 10/11: modes 3/7 without top-right)
 #define LT_T8 5088      // u8  [9][64]   Intra8x8 gather table
 #define LT_ZZ8 5664     // u8  [64]      raster -> 8x8 zig-zag list index
-#define LT_END 5760     // (64-byte aligned: see WaveScratch)
+#define LT_THR 5760      // u16 [52]      KParams::thr_row: int32 exactness bound on |coefficient| per QPY
+#define LT_END 5888     // (64-byte aligned: see WaveScratch)
 
 __global__ void __launch_bounds__(64 * BAND * WG_BANDS, DRYV_WPS)  // (threads, waves per SIMD)
 recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_t* __restrict__ coeffs,
@@ -530,6 +531,7 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   }
   for (int i = threadIdx.x; i < 576; i += blockDim.x) t8[i] = P.t8[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) zz8i[i] = P.zz8i[i];
+  for (int i = threadIdx.x; i < 52; i += blockDim.x) ((uint16_t*)(lds + LT_THR))[i] = P.thr_row[i];
   __syncthreads();  // the only workgroup-level synchronisation: waves are independent from here on
 
   const size_t frameBytes = (size_t)W * H * 384;
@@ -702,6 +704,21 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
         if (act) dma_window(wsAddr + (int)offsetof(WaveScratch, up), src);
       }
       WAVE_SYNC();
+
+      // This kernel computes in int32 throughout; the reference in 64-bit isize. A macroblock with a coefficient beyond
+      // the bound under which the two provably agree (KParams::thr_row; never reached by a conformant stream) is
+      // reported (status bit 1): the library then runs the batch again on the band kernel's wide build.
+      {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const unsigned* cw = (const unsigned*)ws->coef;
+        const s16x2 a = __builtin_bit_cast(s16x2, cw[lane]), b = __builtin_bit_cast(s16x2, cw[lane + 64]),
+                    c = __builtin_bit_cast(s16x2, cw[lane + 128]);
+        const s16x2 mx2 = __builtin_elementwise_max(__builtin_elementwise_max(a, b), c);
+        const s16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(a, b), c);
+        const int hi = max((int)mx2.x, (int)mx2.y), lo = min((int)mn2.x, (int)mn2.y);
+        const int thr = (int)((const uint16_t*)(lds + LT_THR))[qp];
+        if (thr != 0xFFFF && max(hi, -lo) > thr) atomicOr(status, 2u);
+      }
 
       // ================= residuals (need no neighbour: done before waiting for the row above) =====
       int rl[4] = {0, 0, 0, 0};  // luma residual, column organisation (kinds 0 and 2)

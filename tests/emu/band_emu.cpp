@@ -140,7 +140,8 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
     g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, prog.data() + (size_t)2 * n_frames * nBands, modes.data(), &counter, nullptr, 0};
     wv::g_body = body;
     std::vector<std::unique_ptr<wv::Wave>> waves;
-    const int ldsBytes = (g_P.transform8x8 ? dryv::band::T_END_I8 : dryv::band::T_END) + dryv::band::S_BYTES;
+    const int teamBytes = dryv::band::team_bytes(g_P.transform8x8 != 0);
+    const int ldsBytes = (g_P.transform8x8 ? dryv::band::T_END_I8 : dryv::band::T_END) + teamBytes;
     std::vector<std::vector<uint8_t>> teamLds(n_teams, std::vector<uint8_t>(ldsBytes, 0xA5));
     for (int w = 0; w < n_waves; w++) {
       waves.emplace_back(new wv::Wave());
@@ -151,7 +152,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
       wv::g_emu_cur = &waves.back()->st;
       if (w % WPT == 0) {
         dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
-        memset(teamLds[w / WPT].data() + ldsBytes - dryv::band::S_BYTES + dryv::band::S_FLAGS, 0, 64);  // the team's flags
+        memset(teamLds[w / WPT].data() + ldsBytes - teamBytes + dryv::band::S_FLAGS, 0, 64);  // the team's flags
       }
     }
     int live = n_waves;
@@ -164,7 +165,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
         unsigned long long t = 0;
         for (unsigned v : prog) t += v;
         for (auto& L : teamLds)
-          for (int q = 0; q < 64; q += 4) { unsigned v; memcpy(&v, L.data() + ldsBytes - dryv::band::S_BYTES + dryv::band::S_FLAGS + q, 4); t += v; }
+          for (int q = 0; q < 64; q += 4) { unsigned v; memcpy(&v, L.data() + ldsBytes - teamBytes + dryv::band::S_FLAGS + q, 4); t += v; }
         return t;
       };
       const unsigned long long sum0 = progress();

@@ -4,8 +4,9 @@ cross-lane operations, LDS layout, the FRONT/BACK record protocol, band hand-off
 concurrently); the GPU parity tests (`-m gpu`) remain the proof for the machine code. Bit-exact bar. Reference parity
 itself stays unpinned (see oracle/dryv_oracle.c header).
 
-The band kernel serves streams without the 8x8 transform (the library sends the others to the row kernel), so every
-case here is generated with transform_8x8_mode_flag = 0."""
+Every case runs twice: as a stream without the 8x8 transform (the kernel's HAS_I8 = false build, Intra8x8 share moved to
+the other kinds) and, where the case has one, with transform_8x8_mode_flag = 1 (HAS_I8 = true: Intra8x8 residuals, mode
+derivation across Intra4x4 / Intra8x8 neighbours, the 8x8 block chain, quirk Q1)."""
 import os
 import sys
 
@@ -50,10 +51,14 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("with8", [False, True], ids=["no8x8", "8x8"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_emulated_band_kernel_matches_oracle(case):
+def test_emulated_band_kernel_matches_oracle(case, with8):
     name, W, H, frames, skw, fkw = case
-    skw, fkw = dict(skw, i8x8=0.0), dict(fkw, transform_8x8=False)
+    if with8 and not fkw.get("transform_8x8"):
+        pytest.skip("case has no 8x8 variant")
+    if not with8:
+        skw, fkw = dict(skw, i8x8=0.0), dict(fkw, transform_8x8=False)
     fp = abi.make_frame_params(W, H, **fkw)
     mbs, co = synth.generate(fp, synth.config(**skw), 100 + CASES.index(case), 0, frames)
     check(fp, frames, mbs, co)
@@ -66,9 +71,10 @@ def test_emulated_teams_run_concurrently(geo):
     vain): bands below wait for bands above, BACK waits for FRONT's record and FRONT for BACK's buffer. A deadlock in
     any of these protocols stops the emulator with "nothing makes progress"."""
     W, H, frames, teams, first, order = geo
-    fp = abi.make_frame_params(W, H)
-    mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0), 100, 0, frames)
-    check(fp, frames, mbs, co, teams=teams, first=first, order=order)
+    for t8, cfg in ((False, dict(i4x4=0.6, i8x8=0.0)), (True, dict(i4x4=0.35, i8x8=0.4))):
+        fp = abi.make_frame_params(W, H, transform_8x8=t8)
+        mbs, co = synth.generate(fp, synth.config(**cfg), 100, 0, frames)
+        check(fp, frames, mbs, co, teams=teams, first=first, order=order)
 
 
 @pytest.mark.parametrize("nsy,nsc", [(2, 2), (8, 4), (4, 2), (2, 8)])
@@ -86,13 +92,18 @@ def test_emulated_fuzz():
     rng = np.random.default_rng(77)
     for k in range(16):
         W, H, frames = int(rng.integers(1, 14)), int(rng.integers(1, 11)), int(rng.integers(1, 3))
+        t8 = bool(k & 1)
         i4 = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
-        i8 = 0.0
+        i8 = float(rng.choice([0.0, 0.3, 0.6])) if t8 else 0.0
+        if i4 + i8 > 1.0:
+            i4 = 1.0 - i8
         lo = int(rng.integers(0, 40))
         flat = rng.random() < 0.5
-        fkw = dict(cqo_cb=int(rng.integers(-12, 13)), cqo_cr=int(rng.integers(-12, 13)))
+        fkw = dict(cqo_cb=int(rng.integers(-12, 13)), cqo_cr=int(rng.integers(-12, 13)), transform_8x8=t8)
         if not flat:
             fkw.update(scaling4x4=rng.integers(4, 48, size=(6, 16)))
+            if t8:
+                fkw.update(scaling8x8=rng.integers(4, 48, size=(6, 64)))
         skw = dict(i4x4=i4, i8x8=i8, qp=(lo, int(rng.integers(lo, 52))), coded=float(rng.choice([0.2, 0.6, 1.0])),
                    max_level=int(rng.choice([15, 300, 2047])) if flat else 200,
                    legal_modes_only=bool(rng.random() < 0.7), prev_flag=float(rng.choice([0.1, 0.5, 0.9])))
@@ -106,10 +117,12 @@ def test_emulated_full_int16_range_every_qp(qp_range):
     """The FFI carries int16 coefficients and scaling weights up to 255; the reference computes in 64-bit isize.
     Blocks whose coefficients exceed the per-qp int32-exactness bound take the kernel's 64-bit pass."""
     rng = np.random.default_rng(9 + qp_range[0])
-    s4 = rng.integers(1, 256, size=(6, 16))
-    for lists in (dict(), dict(scaling4x4=s4)):
+    s4, s8 = rng.integers(1, 256, size=(6, 16)), rng.integers(1, 256, size=(6, 64))
+    for lists, cfg in ((dict(), dict(i4x4=0.6, i8x8=0.0)), (dict(scaling4x4=s4), dict(i4x4=0.6, i8x8=0.0)),
+                       (dict(transform_8x8=True), dict(i4x4=0.3, i8x8=0.5)),
+                       (dict(transform_8x8=True, scaling4x4=s4, scaling8x8=s8), dict(i4x4=0.3, i8x8=0.5))):
         fp = abi.make_frame_params(6, 5, **lists)
-        mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0, coded=1.0, p0=0.9, decay4=0.97, qp=qp_range), 61, 0, 2)
+        mbs, co = synth.generate(fp, synth.config(coded=1.0, p0=0.9, decay4=0.97, decay8=0.99, qp=qp_range, **cfg), 61, 0, 2)
         scale = rng.choice([1, 40, 700, 6000], size=(co.shape[0], 1))
         co = np.clip(co.astype(np.int64) * scale, -32768, 32767).astype(np.int16)
         check(fp, 2, mbs, co)

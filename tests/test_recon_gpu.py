@@ -299,22 +299,25 @@ def test_two_contexts_in_flight(recon_ctx):
 
 @pytest.mark.parametrize("qp_range", [(0, 24), (25, 40), (41, 51)])
 def test_full_int16_range_every_qp(recon_ctx, qp_range):
-    """The FFI carries int16 coefficients and scaling weights up to 255; the reference computes in 64-bit isize. The
-    band kernel (every batch without the 8x8 transform) flags blocks beyond its per-qp int32-exactness bound and the
-    library re-runs the batch with the kernel's 64-bit build before reporting: bit-exact at every qp."""
+    """The FFI carries int16 coefficients and scaling weights up to 255; the reference computes in 64-bit isize. Both
+    kernels compute in int32 and flag a macroblock beyond the bound under which that is provably the same (band kernel:
+    per block and qp; row kernel: one conservative bound per QPY); the library then re-runs the batch with the band
+    kernel's 64-bit build before reporting: bit-exact at every qp, with and without the 8x8 transform."""
     rng = np.random.default_rng(9 + qp_range[0])
-    s4 = rng.integers(1, 256, size=(6, 16))
-    for lists in (dict(), dict(scaling4x4=s4)):
+    s4, s8 = rng.integers(1, 256, size=(6, 16)), rng.integers(1, 256, size=(6, 64))
+    for lists, cfg in ((dict(), dict(i4x4=0.6, i8x8=0.0)), (dict(scaling4x4=s4), dict(i4x4=0.6, i8x8=0.0)),
+                       (dict(transform_8x8=True), dict(i4x4=0.3, i8x8=0.5)),
+                       (dict(transform_8x8=True, scaling4x4=s4, scaling8x8=s8), dict(i4x4=0.3, i8x8=0.5))):
         fp = abi.make_frame_params(9, 7, **lists)
-        mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0, coded=1.0, p0=0.9, decay4=0.97, qp=qp_range), 61, 0, 3)
+        mbs, co = synth.generate(fp, synth.config(coded=1.0, p0=0.9, decay4=0.97, decay8=0.99, qp=qp_range, **cfg), 61, 0, 3)
         scale = rng.choice([1, 40, 700, 6000], size=(co.shape[0], 1))
         co = np.clip(co.astype(np.int64) * scale, -32768, 32767).astype(np.int16)
         assert_parity(recon_ctx, fp, 3, mbs, co)
 
 
 def test_row_and_band_kernels_agree():
-    """The two kernels in the library (band kernel: default without the 8x8 transform; row kernel: 8x8 streams) on
-    the same 4x4-only batches, each forced through DRYV_RECON_KERNEL in a child process."""
+    """The two kernels in the library (band kernel: default without the 8x8 transform; row kernel: default with it; each
+    serves both) on the same batches, with and without Intra8x8, each forced through DRYV_RECON_KERNEL in a child process."""
     import subprocess
     import sys
     code = (
@@ -326,8 +329,9 @@ def test_row_and_band_kernels_agree():
         "h = hashlib.sha256()\n"
         "for k in range(12):\n"
         "    W, H, frames = int(rng.integers(1, 40)), int(rng.integers(1, 14)), int(rng.integers(1, 6))\n"
-        "    fp = abi.make_frame_params(W, H)\n"
-        "    mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0, legal_modes_only=bool(k & 1)), 500 + k, k, frames)\n"
+        "    t8 = k %% 3 != 0\n"
+        "    fp = abi.make_frame_params(W, H, transform_8x8=t8)\n"
+        "    mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.35 if t8 else 0.0, legal_modes_only=bool(k & 1)), 500 + k, k, frames)\n"
         "    h.update(ctx.reconstruct(fp, frames, mbs, co).tobytes())\n"
         "print('digest', h.hexdigest())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = {}
