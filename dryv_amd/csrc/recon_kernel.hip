@@ -431,7 +431,7 @@ constexpr bool HAS_I8 = true;
 #define DRYV_GPOLL_SLEEP 2  // the same between two polls of a progress word in L2 (band boundaries)
 #endif
 #ifndef DRYV_WPS
-#define DRYV_WPS 8  // resident waves per SIMD the kernel is compiled for (512 VGPRs / DRYV_WPS each)
+#define DRYV_WPS 6  // resident waves per SIMD the kernel is compiled for (80 VGPRs: no spills; 8 (64 VGPRs, 4 spilled) measured the same on C3)
 #endif
 #ifndef WG_BANDS
 #define WG_BANDS 2 // independent bands per workgroup: they share nothing but the constant tables (5.7 KB)
