@@ -120,7 +120,10 @@ WV void wait_vm(int n) {
 #endif
 WV void sleep_short() { __builtin_amdgcn_s_sleep(DRYV_BAND_SLEEP); }
 WV void sleep_long() { __builtin_amdgcn_s_sleep(32); }
-WV void sleep_team() { __builtin_amdgcn_s_sleep(1); }  // between two polls of the partner wave's LDS flag
+#ifndef DRYV_TEAM_SLEEP
+#define DRYV_TEAM_SLEEP 1
+#endif
+WV void sleep_team() { __builtin_amdgcn_s_sleep(DRYV_TEAM_SLEEP); }  // between two polls of the partner wave's LDS flag
 WV void compiler_fence() { asm volatile("" ::: "memory"); }
 // the value, behind a barrier the optimiser cannot see through: what is derived from it is recomputed, not kept live
 WV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
