@@ -39,6 +39,17 @@ def _load():
         _lib.dryv_h264_encode_idr_cropped.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                       C.c_size_t]
         _lib.dryv_h264_crop.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.dryv_h264_parse_all.restype = C.c_void_p
+        _lib.dryv_h264_parse_all.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        _lib.dryv_h264_batch_free.argtypes = [C.c_void_p]
+        for n, rt in (("pictures", C.c_size_t), ("skipped", C.c_size_t), ("params", C.c_void_p), ("mbs", C.c_void_p),
+                      ("coeffs", C.c_void_p), ("tails_ok", C.c_int)):
+            getattr(_lib, "dryv_h264_batch_" + n).restype = rt
+            getattr(_lib, "dryv_h264_batch_" + n).argtypes = [C.c_void_p]
+        _lib.dryv_h264_batch_crop.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.dryv_h264_encode_stream.restype = C.c_longlong
+        _lib.dryv_h264_encode_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_size_t]
     return _lib
 
 
@@ -88,6 +99,54 @@ def encode_idr(fp, mbs, coeffs, slice_qp=26, crop=None):
     def call(buf):
         return lib.dryv_h264_encode_idr_cropped(C.addressof(fp), mbs.ctypes.data, coeffs.ctypes.data, slice_qp,
                                                 cr.ctypes.data, buf.ctypes.data, buf.size)
+    r = call(out)
+    if r < 0:
+        out = np.empty(-r, dtype=np.uint8)
+        r = call(out)
+    if r <= 0:
+        raise H264Error(lib.dryv_h264_last_error().decode())
+    return out[:r].tobytes()
+
+
+def parse_all_islices(data, max_pictures=0):
+    """Every picture of an .mp4 / Annex-B stream that is a single I slice, as one batch for the reconstruction ABI.
+    Returns (fp, n_pictures, mbs, coeffs, info); inter pictures in between are skipped (info["skipped"])."""
+    lib = _load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    h = lib.dryv_h264_parse_all(buf.ctypes.data, buf.size, int(max_pictures))
+    if not h:
+        raise H264Error(lib.dryv_h264_last_error().decode())
+    try:
+        n_pic = lib.dryv_h264_batch_pictures(h)
+        fp = abi.FrameParams()
+        C.memmove(C.addressof(fp), lib.dryv_h264_batch_params(h), C.sizeof(fp))
+        n = n_pic * fp.pic_width_in_mbs * fp.pic_height_in_mbs
+        mbs = np.empty(n, dtype=abi.MB_DESC_DTYPE)
+        C.memmove(mbs.ctypes.data, lib.dryv_h264_batch_mbs(h), n * 16)
+        coeffs = np.empty((n, 384), dtype=np.int16)
+        C.memmove(coeffs.ctypes.data, lib.dryv_h264_batch_coeffs(h), n * 768)
+        crop = np.zeros(4, dtype=np.int32)
+        lib.dryv_h264_batch_crop(h, crop.ctypes.data)
+        info = {"skipped": int(lib.dryv_h264_batch_skipped(h)), "tails_ok": int(lib.dryv_h264_batch_tails_ok(h)),
+                "crop": tuple(int(v) for v in crop)}
+    finally:
+        lib.dryv_h264_batch_free(h)
+    return fp, int(n_pic), mbs, coeffs, info
+
+
+def encode_stream(fp, n_pictures, mbs, coeffs, slice_qp=26, crop=None):
+    """n_pictures pictures (flat scaling lists) -> one all-intra Annex-B stream: SPS, PPS, one IDR slice per picture."""
+    lib = _load()
+    mbs = np.ascontiguousarray(mbs)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    n = n_pictures * fp.pic_width_in_mbs * fp.pic_height_in_mbs
+    assert mbs.size == n and coeffs.size == n * 384
+    cr = np.asarray(crop if crop is not None else (0, 0, 0, 0), dtype=np.int32)
+    out = np.empty(64 + n * 1200, dtype=np.uint8)
+
+    def call(buf):
+        return lib.dryv_h264_encode_stream(C.addressof(fp), int(n_pictures), mbs.ctypes.data, coeffs.ctypes.data, slice_qp,
+                                           cr.ctypes.data, buf.ctypes.data, buf.size)
     r = call(out)
     if r < 0:
         out = np.empty(-r, dtype=np.uint8)

@@ -5,6 +5,7 @@
 // in.batch: dryv_frame_params (496 B) | u32 n_frames | dryv_mb_desc[n] | int16 coeffs[n][384]
 // (written by tests/test_host_harness.py from the synthetic generator). Frames are written back to back.
 //
+//   frame_harness decode-all <in.mp4 | in.h264> <out.yuv>      every intra picture of the stream as one batch
 //   frame_harness decode <in.mp4 | in.h264> <out.yuv>
 // BASELINE.json configs[0], end to end: what `dryv <path>` does for its one decoded picture (video/decoder.rs:88-143:
 // sample 0 of the video track -> slice NAL -> CABAC macroblock loop -> Frame::decode per macroblock ->
@@ -82,8 +83,57 @@ static int decode_file(const char* in, const char* outp) {
   return 0;
 }
 
+// frame_harness decode-all <in.mp4 | in.h264> <out.yuv>: every intra picture of the stream (h264_islice.hpp:
+// parse_all_islices) as ONE batch through dryv_recon_submit / dryv_recon_wait -- what INTEGRATION.md recommends for a
+// dryv that decodes more than sample 0. Pictures are written back to back in write_to_yuv_file order.
+static int decode_all(const char* in, const char* outp) {
+  FILE* f = std::fopen(in, "rb");
+  if (!f) { std::perror("open"); return 2; }
+  std::vector<uint8_t> data;
+  uint8_t buf[65536];
+  size_t k;
+  while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
+  std::fclose(f);
+  std::vector<dryv::h264::ParsedFrame> P;
+  size_t skipped = 0;
+  try {
+    P = dryv::h264::parse_all_islices(data.data(), data.size(), (size_t)-1, &skipped);
+  } catch (const dryv::h264::Error& e) {
+    std::fprintf(stderr, "parse: %s\n", e.what.c_str());
+    return 6;
+  }
+  const dryv_frame_params fp = P[0].fp;
+  const size_t per = (size_t)fp.pic_width_in_mbs * fp.pic_height_in_mbs;
+  std::vector<dryv_mb_desc> mbs;
+  std::vector<int16_t> co;
+  bool tails = true;
+  for (const auto& F : P) {
+    if (std::memcmp(&F.fp, &fp, sizeof fp) != 0) { std::fprintf(stderr, "parse: parameters change inside the stream\n"); return 6; }
+    mbs.insert(mbs.end(), F.mbs.begin(), F.mbs.end());
+    co.insert(co.end(), F.coeffs.begin(), F.coeffs.end());
+    tails = tails && F.tail_ok;
+  }
+  std::printf("parsed %zu intra pictures of %ux%u macroblocks (%zu other coded slices skipped), tails %s\n", P.size(),
+              fp.pic_width_in_mbs, fp.pic_height_in_mbs, skipped, tails ? "ok" : "BAD");
+  if (!tails) return 6;
+  dryv_recon_ctx* ctx = nullptr;
+  int st = dryv_recon_create(&ctx, 0);
+  if (st != DRYV_OK) { std::fprintf(stderr, "dryv_recon_create: %s\n", dryv_recon_strerror(st)); return 3; }
+  std::vector<uint8_t> yuv(P.size() * per * 384);
+  st = dryv_recon_submit(ctx, &fp, (uint32_t)P.size(), mbs.data(), co.data());
+  if (st == DRYV_OK) st = dryv_recon_wait(ctx, yuv.data(), yuv.size());
+  if (st != DRYV_OK) { std::fprintf(stderr, "reconstruct: %s\n", dryv_recon_strerror(st)); return 5; }
+  FILE* out = std::fopen(outp, "wb");
+  if (!out) return 2;
+  std::fwrite(yuv.data(), 1, yuv.size(), out);
+  std::fclose(out);
+  dryv_recon_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 4 && std::strcmp(argv[1], "decode") == 0) return decode_file(argv[2], argv[3]);
+  if (argc == 4 && std::strcmp(argv[1], "decode-all") == 0) return decode_all(argv[2], argv[3]);
   if (argc != 3) { std::fprintf(stderr, "usage: %s in.batch out.yuv\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("open"); return 2; }

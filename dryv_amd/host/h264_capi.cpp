@@ -76,4 +76,60 @@ long long dryv_h264_encode_idr_cropped(const dryv_frame_params* fp, const dryv_m
   }
 }
 
+/* ---- batches of pictures ------------------------------------------------------------------------------------------------ */
+struct dryv_h264_batch {
+  std::vector<ParsedFrame> F;
+  std::vector<dryv_mb_desc> mbs;
+  std::vector<int16_t> coeffs;
+  size_t skipped = 0;
+};
+/* Parses every picture of the stream that is one I slice (at most max_pictures; 0 = all). NULL on failure. */
+dryv_h264_batch* dryv_h264_parse_all(const uint8_t* data, size_t n, size_t max_pictures) {
+  try {
+    auto* b = new dryv_h264_batch;
+    b->F = parse_all_islices(data, n, max_pictures ? max_pictures : (size_t)-1, &b->skipped);
+    for (const ParsedFrame& f : b->F) {
+      if (memcmp(&f.fp, &b->F[0].fp, sizeof(f.fp)) != 0) {
+        delete b;
+        g_err = "pictures of different parameters in one stream";
+        return nullptr;
+      }
+      b->mbs.insert(b->mbs.end(), f.mbs.begin(), f.mbs.end());
+      b->coeffs.insert(b->coeffs.end(), f.coeffs.begin(), f.coeffs.end());
+    }
+    return b;
+  } catch (const Error& e) {
+    g_err = e.what;
+    return nullptr;
+  }
+}
+void dryv_h264_batch_free(dryv_h264_batch* b) { delete b; }
+size_t dryv_h264_batch_pictures(const dryv_h264_batch* b) { return b->F.size(); }
+size_t dryv_h264_batch_skipped(const dryv_h264_batch* b) { return b->skipped; }   /* coded slices that were not whole intra pictures */
+const dryv_frame_params* dryv_h264_batch_params(const dryv_h264_batch* b) { return &b->F[0].fp; }
+const dryv_mb_desc* dryv_h264_batch_mbs(const dryv_h264_batch* b) { return b->mbs.data(); }
+const int16_t* dryv_h264_batch_coeffs(const dryv_h264_batch* b) { return b->coeffs.data(); }
+/* 1 if every picture's CABAC data ended at its terminating bin with only the stop bit and zeros behind it */
+int dryv_h264_batch_tails_ok(const dryv_h264_batch* b) {
+  for (const ParsedFrame& f : b->F)
+    if (!f.tail_ok) return 0;
+  return 1;
+}
+void dryv_h264_batch_crop(const dryv_h264_batch* b, int* crop4) {
+  for (int k = 0; k < 4; k++) crop4[k] = b->F[0].crop[k];
+}
+/* n_pictures pictures (records / coefficients back to back) as one all-intra Annex-B stream: SPS, PPS, IDR slices. */
+long long dryv_h264_encode_stream(const dryv_frame_params* fp, int n_pictures, const dryv_mb_desc* mbs, const int16_t* coeffs,
+                                  int slice_qp, const int* crop4, uint8_t* out, size_t cap) {
+  try {
+    const std::vector<uint8_t> v = encode_idr_annexb(*fp, mbs, coeffs, slice_qp, crop4, n_pictures);
+    if (v.size() > cap) return -(long long)v.size();
+    memcpy(out, v.data(), v.size());
+    return (long long)v.size();
+  } catch (const Error& e) {
+    g_err = e.what;
+    return 0;
+  }
+}
+
 }  // extern "C"

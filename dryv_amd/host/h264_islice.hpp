@@ -887,9 +887,10 @@ inline bool find_atom(const uint8_t* p, size_t n, const char* name, const uint8_
   return false;
 }
 
-// ISO-BMFF: the first video track's avcC (SPS / PPS, NAL length size) and its first sample (video/decoder.rs:88: only
-// sample 0 is decoded), split into length-prefixed NAL units (sample/nal.rs:232-253).
-inline Stream demux_mp4_first_sample(const uint8_t* f, size_t n) {
+// ISO-BMFF: the first video track's avcC (SPS / PPS, NAL length size) and its first `max_samples` samples (the reference
+// decodes only sample 0: video/decoder.rs:88), split into length-prefixed NAL units (sample/nal.rs:232-253). Sample
+// positions: chunk offsets (stco / co64) + sample-to-chunk runs (stsc) + sample sizes (stsz).
+inline Stream demux_mp4(const uint8_t* f, size_t n, size_t max_samples) {
   const uint8_t *moov, *trak, *mdia, *minf, *stbl, *stsd, *q;
   size_t nmoov, ntrak, nmdia, nminf, nstbl, nstsd, nq;
   if (!find_atom(f, n, "moov", moov, nmoov)) fail("mp4: no moov atom");
@@ -927,29 +928,44 @@ inline Stream demux_mp4_first_sample(const uint8_t* f, size_t n) {
     take_nal(S, q + o, l);
     o += l;
   }
-  // first sample: size from stsz, offset = first chunk offset (stco / co64)
-  const uint8_t *stsz, *stco;
-  size_t nstsz, nstco;
+  const uint8_t *stsz, *stco, *stsc;
+  size_t nstsz, nstco, nstsc;
   if (!find_atom(stbl, nstbl, "stsz", stsz, nstsz) || nstsz < 12) fail("mp4: no stsz");
-  uint32_t size0 = be32(stsz + 4);
-  if (size0 == 0) {
-    if (nstsz < 16) fail("mp4: empty stsz");
-    size0 = be32(stsz + 12);
-  }
-  uint64_t off0;
-  if (find_atom(stbl, nstbl, "stco", stco, nstco) && nstco >= 12) off0 = be32(stco + 8);
-  else if (find_atom(stbl, nstbl, "co64", stco, nstco) && nstco >= 16) off0 = be64(stco + 8);
+  const uint32_t fixedSize = be32(stsz + 4), nSamples = be32(stsz + 8);
+  if (fixedSize == 0 && nstsz < 12 + 4 * (size_t)nSamples) fail("mp4: stsz truncated");
+  bool co64 = false;
+  if (find_atom(stbl, nstbl, "stco", stco, nstco) && nstco >= 8) co64 = false;
+  else if (find_atom(stbl, nstbl, "co64", stco, nstco) && nstco >= 8) co64 = true;
   else fail("mp4: no chunk offsets");
-  if (off0 + size0 > n) fail("mp4: sample outside the file");
-  const uint8_t* sp = f + off0;
-  size_t so = 0;
-  while (so + lenSize <= size0) {
-    size_t l = 0;
-    for (int k = 0; k < lenSize; k++) l = (l << 8) | sp[so + k];
-    so += lenSize;
-    if (so + l > size0) fail("mp4: NAL unit outside the sample");
-    take_nal(S, sp + so, l);
-    so += l;
+  const uint32_t nChunks = be32(stco + 4);
+  if (nstco < 8 + (size_t)nChunks * (co64 ? 8 : 4)) fail("mp4: chunk offset table truncated");
+  // stsc: runs of chunks with the same number of samples; absent or empty = one sample per chunk
+  uint32_t nRuns = 0;
+  if (find_atom(stbl, nstbl, "stsc", stsc, nstsc) && nstsc >= 8) {
+    nRuns = be32(stsc + 4);
+    if (nstsc < 8 + 12 * (size_t)nRuns) fail("mp4: stsc truncated");
+  }
+  size_t sample = 0;
+  uint32_t run = 0;
+  for (uint32_t c = 0; c < nChunks && sample < nSamples && sample < max_samples; c++) {
+    while (run + 1 < nRuns && be32(stsc + 8 + 12 * (run + 1)) <= c + 1) run++;
+    const uint32_t perChunk = nRuns ? be32(stsc + 8 + 12 * run + 4) : 1;
+    uint64_t off = co64 ? be64(stco + 8 + 8 * (size_t)c) : be32(stco + 8 + 4 * (size_t)c);
+    for (uint32_t k = 0; k < perChunk && sample < nSamples && sample < max_samples; k++, sample++) {
+      const uint32_t size = fixedSize ? fixedSize : be32(stsz + 12 + 4 * sample);
+      if (off + size > n) fail("mp4: sample outside the file");
+      const uint8_t* sp = f + off;
+      size_t so = 0;
+      while (so + lenSize <= size) {
+        size_t l = 0;
+        for (int q2 = 0; q2 < lenSize; q2++) l = (l << 8) | sp[so + q2];
+        so += lenSize;
+        if (so + l > size) fail("mp4: NAL unit outside the sample");
+        take_nal(S, sp + so, l);
+        so += l;
+      }
+      off += size;
+    }
   }
   return S;
 }
@@ -976,16 +992,52 @@ inline Stream demux_annexb(const uint8_t* f, size_t n) {
 
 inline ParsedFrame parse_first_islice(const uint8_t* f, size_t n) {
   const bool mp4 = n >= 12 && memcmp(f + 4, "ftyp", 4) == 0;
-  Stream S = mp4 ? demux_mp4_first_sample(f, n) : demux_annexb(f, n);
+  Stream S = mp4 ? demux_mp4(f, n, 1) : demux_annexb(f, n);
   if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
   if (S.slices.empty()) fail("no coded slice");
   return parse_islice_nal(S.slices[0].data(), S.slices[0].size(), S.sps, S.pps);
 }
 
+// Whether a coded slice NAL unit starts a picture that consists of one I slice (what this parser decodes).
+inline bool is_whole_picture_islice(const std::vector<uint8_t>& nal) {
+  if (nal.size() < 2) return false;
+  const std::vector<uint8_t> rbsp = unescape(nal.data() + 1, std::min<size_t>(nal.size() - 1, 16));
+  BitReader r{rbsp.data(), rbsp.size(), 0};
+  try {
+    const unsigned first_mb = r.ue(), type = r.ue();
+    return first_mb == 0 && type % 5 == 2;
+  } catch (const Error&) {
+    return false;
+  }
+}
+
+// Every picture of the stream that is a single I slice, up to max_pictures (the reference stops after sample 0:
+// decoder.rs:88, quirk Q9 -- a batch of pictures is this build's own unit of work), all under the stream's first SPS /
+// PPS. Inter pictures in between are skipped; their count is returned in *skipped.
+inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, size_t max_pictures, size_t* skipped = nullptr) {
+  const bool mp4 = n >= 12 && memcmp(f + 4, "ftyp", 4) == 0;
+  Stream S = mp4 ? demux_mp4(f, n, (size_t)-1) : demux_annexb(f, n);
+  if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
+  std::vector<ParsedFrame> out;
+  size_t skip = 0;
+  for (const std::vector<uint8_t>& nal : S.slices) {
+    if (out.size() >= max_pictures) break;
+    if (!is_whole_picture_islice(nal)) {
+      skip++;
+      continue;
+    }
+    out.push_back(parse_islice_nal(nal.data(), nal.size(), S.sps, S.pps));
+  }
+  if (skipped) *skipped = skip;
+  if (out.empty()) fail("no intra picture");
+  return out;
+}
+
 // ---- encoder: one IDR picture as an Annex-B byte stream (SPS, PPS, one I slice) ------------------------------------------
 // crop: optional frame cropping rectangle in luma samples (left, right, top, bottom; even), written to the SPS
+// n_pictures > 1: an all-intra stream, one IDR picture after the other (mbs / coeffs hold them back to back)
 inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const dryv_mb_desc* mbs, const int16_t* coeffs,
-                                              int slice_qp = 26, const int* crop = nullptr) {
+                                              int slice_qp = 26, const int* crop = nullptr, int n_pictures = 1) {
   const int W = fp.pic_width_in_mbs, H = fp.pic_height_in_mbs;
   for (int l = 0; l < 6; l++) {
     for (int k = 0; k < 16; k++)
@@ -1047,13 +1099,13 @@ inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const
     w.trailing();
     append_nal_annexb(out, 0x68, w.out);
   }
-  {
+  for (int pic = 0; pic < n_pictures; pic++, mbs += W * H, coeffs += (size_t)W * H * 384) {
     BitWriter w;  // slice header (7.3.3), IDR, I slice
     w.ue(0);
     w.ue(7);
     w.ue(0);
     w.bits(0, 4);  // frame_num
-    w.ue(0);       // idr_pic_id
+    w.ue((unsigned)(pic & 1));  // idr_pic_id: consecutive IDR pictures must differ (7.4.3)
     w.bit(0);
     w.bit(0);  // dec_ref_pic_marking: no_output_of_prior_pics_flag, long_term_reference_flag
     w.se(slice_qp - 26);

@@ -117,3 +117,35 @@ def test_frame_cropping_rectangle_round_trips():
     assert np.array_equal(co2, co)
     with pytest.raises(h264.H264Error):
         h264.encode_idr(fp, mbs, co, crop=(1, 0, 0, 0))      # odd: not expressible in crop units
+
+
+def test_all_intra_stream_round_trip():
+    """A batch of pictures -> one all-intra Annex-B stream (SPS, PPS, an IDR slice per picture) -> parse_all_islices: the
+    batch comes back picture for picture, ready for one submit. (The reference stops after sample 0, quirk Q9: batches are
+    this build's own unit of work.)"""
+    fp = abi.make_frame_params(9, 6, transform_8x8=True)
+    frames = 5
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3), 5151, 0, frames)
+    stream = h264.encode_stream(fp, frames, mbs, co, slice_qp=int(mbs["qp"][0]))
+    fp2, n2, mbs2, co2, info = h264.parse_all_islices(stream)
+    assert n2 == frames and bytes(fp2) == bytes(fp) and info["tails_ok"] == 1 and info["skipped"] == 0
+    assert np.array_equal(co2, co) and np.array_equal(mbs2["mb_kind"], mbs["mb_kind"])
+    st1, y1 = oracle.reconstruct(fp, frames, mbs, co)
+    st2, y2 = oracle.reconstruct(fp2, n2, mbs2, co2)
+    assert st1 == 0 and st2 == 0 and np.array_equal(y1, y2)
+    # a limit on the number of pictures, and the single-picture entry point on the same stream
+    assert h264.parse_all_islices(stream, max_pictures=2)[1] == 2
+    fp1, mbs1, co1, _ = h264.parse_first_islice(stream)
+    assert np.array_equal(co1, co[:54])
+
+
+def test_real_mp4_intra_pictures_among_inter_ones():
+    """realshort.mp4 is an ordinary IPB stream: sample positions come from stco / stsc / stsz, the intra pictures are
+    parsed (each must end at its terminating bin), the inter pictures are counted and skipped."""
+    data = open(FIXTURE, "rb").read()
+    fp, n_pic, mbs, co, info = h264.parse_all_islices(data)
+    assert n_pic >= 1 and info["tails_ok"] == 1 and info["skipped"] >= 1
+    fp1, mbs1, co1, _ = h264.parse_first_islice(data)
+    assert bytes(fp) == bytes(fp1) and np.array_equal(co[:300], co1) and np.array_equal(mbs[:300], mbs1)
+    st, yuv = oracle.reconstruct(fp, n_pic, mbs, co)
+    assert st == 0

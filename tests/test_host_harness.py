@@ -59,3 +59,25 @@ def test_config1_real_mp4_end_to_end(tmp_path):
     st, want = oracle.reconstruct(fp, 1, mbs, co)
     got = np.fromfile(str(out), dtype=np.uint8)
     assert st == 0 and got.size == 320 * 240 * 3 // 2 and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_all_intra_stream_end_to_end(tmp_path):
+    """An all-intra Annex-B stream of several pictures (written by the CABAC encoder) and the two intra pictures of the
+    real .mp4, each through `frame_harness decode-all`: host parse of every picture -> one batch -> GPU -> pictures back to
+    back, equal to the oracle's reconstruction of the same batch."""
+    from dryv_amd import h264
+    exe = _build.build_harness()
+    fp = abi.make_frame_params(11, 7, transform_8x8=True)
+    frames = 6
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3), 77, 0, frames)
+    src = tmp_path / "intra.h264"
+    src.write_bytes(h264.encode_stream(fp, frames, mbs, co, slice_qp=int(mbs["qp"][0])))
+    for path, n_expect in ((str(src), frames), (FIXTURE, 2)):
+        out = tmp_path / "all.yuv"
+        r = subprocess.run([exe, "decode-all", path, str(out)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "tails ok" in r.stdout and ("parsed %d intra pictures" % n_expect) in r.stdout, (r.stdout, r.stderr)
+        fpp, n_pic, pm, pc, info = h264.parse_all_islices(open(path, "rb").read())
+        st, want = oracle.reconstruct(fpp, n_pic, pm, pc)
+        got = np.fromfile(str(out), dtype=np.uint8)
+        assert st == 0 and n_pic == n_expect and np.array_equal(got, want)
