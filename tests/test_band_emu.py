@@ -126,3 +126,32 @@ def test_emulated_full_int16_range_every_qp(qp_range):
         scale = rng.choice([1, 40, 700, 6000], size=(co.shape[0], 1))
         co = np.clip(co.astype(np.int64) * scale, -32768, 32767).astype(np.int16)
         check(fp, 2, mbs, co)
+
+
+def test_emulated_fast_path_at_its_exactness_bound():
+    """Adversarial input for the int32 fast path: every coefficient of every block sits exactly AT the per-qp bound under
+    which the kernel stays in 32-bit arithmetic (KParams thr4 / thr8, recomputed here), with the sign patterns that
+    maximise the butterflies' growth (all equal; the first basis functions' signs). One above the bound takes the 64-bit
+    pass. Both must equal the oracle's 64-bit result bit for bit."""
+    V4 = np.array([[10, 16, 13], [11, 18, 14], [13, 20, 16], [14, 23, 18], [16, 25, 20], [18, 29, 23]])
+    V8 = np.array([[20, 18, 32, 19, 25, 24], [22, 19, 35, 21, 28, 26], [26, 23, 42, 24, 33, 31], [28, 25, 45, 26, 35, 33],
+                   [32, 28, 51, 30, 40, 38], [36, 32, 58, 34, 46, 43]])
+    rng = np.random.default_rng(4)
+    for t8 in (False, True):
+        fp = abi.make_frame_params(4, 4, transform_8x8=t8)
+        for qp in (0, 11, 23, 24, 35, 36, 41, 47, 51):
+            qd, qm = qp // 6, qp % 6
+            thr4 = min((1 << 26) // ((16 * V4[qm].max()) << max(qd - 4, 0)), 32767)
+            thr8 = min((1 << 23) // ((16 * V8[qm].max()) << max(qd - 6, 0)), 32767)
+            for bump in (0, 1):
+                cfg = synth.config(i4x4=0.4, i8x8=0.4 if t8 else 0.0, coded=1.0, qp=(qp, qp))
+                mbs, co = synth.generate(fp, cfg, 900 + qp, 0, 1)
+                co = co.astype(np.int64)
+                for a in range(co.shape[0]):
+                    lim = (thr8 if mbs["mb_kind"][a] == 1 else thr4) + bump
+                    lim = min(lim, 32767)
+                    pat = rng.integers(0, 3)
+                    sign = np.ones(384, dtype=np.int64) if pat == 0 else (np.where(np.arange(384) % 2, -1, 1) if pat == 1
+                                                                        else rng.choice([-1, 1], size=384))
+                    co[a] = sign * lim
+                check(fp, 1, mbs, co.astype(np.int16))

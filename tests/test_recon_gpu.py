@@ -476,3 +476,30 @@ def test_output_stage_crop_and_nv12(recon_ctx, geo):
         recon_ctx.wait_packed(abi.make_output_desc(abi.OUT_I420, (0, 0, 16 * H, 0)))
     recon_ctx._keep = (mbs, co, fp)
     assert np.array_equal(recon_ctx.wait(), full)
+
+
+def test_exactness_bound_adversarial(recon_ctx):
+    """Every coefficient exactly at (and one above) the per-qp bound of the band kernel's 32-bit path, with the sign patterns
+    that maximise the butterflies' growth; streams with the 8x8 transform go through the row kernel's conservative bound
+    and the re-run instead. All must equal the oracle's 64-bit arithmetic bit for bit."""
+    V4 = np.array([[10, 16, 13], [11, 18, 14], [13, 20, 16], [14, 23, 18], [16, 25, 20], [18, 29, 23]])
+    V8 = np.array([[20, 18, 32, 19, 25, 24], [22, 19, 35, 21, 28, 26], [26, 23, 42, 24, 33, 31], [28, 25, 45, 26, 35, 33],
+                   [32, 28, 51, 30, 40, 38], [36, 32, 58, 34, 46, 43]])
+    rng = np.random.default_rng(4)
+    for t8 in (False, True):
+        fp = abi.make_frame_params(6, 5, transform_8x8=t8)
+        for qp in (0, 23, 24, 35, 36, 41, 51):
+            qd, qm = qp // 6, qp % 6
+            thr4 = min((1 << 26) // ((16 * V4[qm].max()) << max(qd - 4, 0)), 32767)
+            thr8 = min((1 << 23) // ((16 * V8[qm].max()) << max(qd - 6, 0)), 32767)
+            for bump in (0, 1):
+                cfg = synth.config(i4x4=0.4, i8x8=0.4 if t8 else 0.0, coded=1.0, qp=(qp, qp))
+                mbs, co = synth.generate(fp, cfg, 900 + qp, 0, 2)
+                co = co.astype(np.int64)
+                for a in range(co.shape[0]):
+                    lim = min((thr8 if mbs["mb_kind"][a] == 1 else thr4) + bump, 32767)
+                    pat = rng.integers(0, 3)
+                    sign = np.ones(384, dtype=np.int64) if pat == 0 else (np.where(np.arange(384) % 2, -1, 1) if pat == 1
+                                                                        else rng.choice([-1, 1], size=384))
+                    co[a] = sign * lim
+                assert_parity(recon_ctx, fp, 2, mbs, co.astype(np.int16))
