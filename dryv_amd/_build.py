@@ -72,7 +72,7 @@ def build_harness(force=False):
     srcs = [os.path.join(host, f) for f in ("frame_harness.cpp", "frame.hpp", "h264_islice.hpp", "cabac_tables.inc")]
     build_recon(force)
     if force or _stale(HARNESS, srcs + [RECON_SO]):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", "-o", HARNESS, srcs[0], "-L" + LIB, "-ldryv_recon",
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-o", HARNESS, srcs[0], "-L" + LIB, "-ldryv_recon",
               "-Wl,-rpath," + LIB, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
     return HARNESS
 

@@ -17,7 +17,7 @@ def build(force=False):
     srcs = [os.path.join(host, f) for f in ("h264_capi.cpp", "h264_islice.hpp", "cabac_tables.inc")]
     os.makedirs(_build.LIB, exist_ok=True)
     if force or _build._stale(SO, srcs + [os.path.join(_build.HERE, "..", "include", "dryv_recon.h")]):
-        _build._run(["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", "-o", SO, srcs[0]])
+        _build._run(["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", "-pthread", "-o", SO, srcs[0]])
     return SO
 
 
@@ -41,6 +41,13 @@ def _load():
         _lib.dryv_h264_crop.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dryv_h264_parse_all.restype = C.c_void_p
         _lib.dryv_h264_parse_all.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        _lib.dryv_h264_stream_params.restype = C.c_longlong
+        _lib.dryv_h264_stream_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.dryv_h264_parse_all_into.restype = C.c_longlong
+        _lib.dryv_h264_parse_all_into.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p, C.c_void_p]
+        _lib.dryv_h264_parse_all_mt.restype = C.c_void_p
+        _lib.dryv_h264_parse_all_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint]
         _lib.dryv_h264_batch_free.argtypes = [C.c_void_p]
         for n, rt in (("pictures", C.c_size_t), ("skipped", C.c_size_t), ("params", C.c_void_p), ("mbs", C.c_void_p),
                       ("coeffs", C.c_void_p), ("tails_ok", C.c_int)):
@@ -108,12 +115,13 @@ def encode_idr(fp, mbs, coeffs, slice_qp=26, crop=None):
     return out[:r].tobytes()
 
 
-def parse_all_islices(data, max_pictures=0):
+def parse_all_islices(data, max_pictures=0, threads=1):
     """Every picture of an .mp4 / Annex-B stream that is a single I slice, as one batch for the reconstruction ABI.
-    Returns (fp, n_pictures, mbs, coeffs, info); inter pictures in between are skipped (info["skipped"])."""
+    Returns (fp, n_pictures, mbs, coeffs, info); inter pictures in between are skipped (info["skipped"]). threads:
+    pictures are parsed in parallel (0 = all hardware threads)."""
     lib = _load()
     buf = np.frombuffer(data, dtype=np.uint8)
-    h = lib.dryv_h264_parse_all(buf.ctypes.data, buf.size, int(max_pictures))
+    h = lib.dryv_h264_parse_all_mt(buf.ctypes.data, buf.size, int(max_pictures), int(threads))
     if not h:
         raise H264Error(lib.dryv_h264_last_error().decode())
     try:
@@ -154,3 +162,35 @@ def encode_stream(fp, n_pictures, mbs, coeffs, slice_qp=26, crop=None):
     if r <= 0:
         raise H264Error(lib.dryv_h264_last_error().decode())
     return out[:r].tobytes()
+
+
+def parse_all_islices_into(data, mbs_out, coeffs_out, max_pictures=0, threads=0):
+    """parse_all_islices straight into the caller's batch buffers (numpy arrays of abi.MB_DESC_DTYPE / int16, e.g. page-locked
+    ones from ReconContext.alloc_host): no intermediate copies. Returns (fp, n_pictures, info)."""
+    lib = _load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    fp = abi.FrameParams()
+    info = np.zeros(4, dtype=np.int64)
+    capacity = min(mbs_out.size, coeffs_out.size // 384)   # in macroblocks; the C side counts pictures
+    # capacity in pictures is only known once the SPS is parsed: pass macroblocks / 1 and let the C side check per picture
+    n = lib.dryv_h264_parse_all_into(buf.ctypes.data, buf.size, int(max_pictures), int(threads), mbs_out.ctypes.data,
+                                     coeffs_out.ctypes.data, _capacity_pictures(data, capacity), C.addressof(fp), info.ctypes.data)
+    if n <= 0:
+        raise H264Error(lib.dryv_h264_last_error().decode())
+    return fp, int(n), {"skipped": int(info[1]), "tails_ok": int(info[2])}
+
+
+def stream_params(data):
+    """(fp, n_coded_slices) from the stream's parameter sets alone: what a caller needs to size its batch buffers."""
+    lib = _load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    fp = abi.FrameParams()
+    n = lib.dryv_h264_stream_params(buf.ctypes.data, buf.size, C.addressof(fp))
+    if n <= 0:
+        raise H264Error(lib.dryv_h264_last_error().decode())
+    return fp, int(n)
+
+
+def _capacity_pictures(data, capacity_mbs):
+    fp, _ = stream_params(data)
+    return capacity_mbs // (fp.pic_width_in_mbs * fp.pic_height_in_mbs)

@@ -84,10 +84,15 @@ struct dryv_h264_batch {
   size_t skipped = 0;
 };
 /* Parses every picture of the stream that is one I slice (at most max_pictures; 0 = all). NULL on failure. */
+dryv_h264_batch* dryv_h264_parse_all_mt(const uint8_t* data, size_t n, size_t max_pictures, unsigned n_threads);
 dryv_h264_batch* dryv_h264_parse_all(const uint8_t* data, size_t n, size_t max_pictures) {
+  return dryv_h264_parse_all_mt(data, n, max_pictures, 1);
+}
+/* n_threads: pictures are parsed in parallel (0 = one thread per hardware thread) */
+dryv_h264_batch* dryv_h264_parse_all_mt(const uint8_t* data, size_t n, size_t max_pictures, unsigned n_threads) {
   try {
     auto* b = new dryv_h264_batch;
-    b->F = parse_all_islices(data, n, max_pictures ? max_pictures : (size_t)-1, &b->skipped);
+    b->F = parse_all_islices(data, n, max_pictures ? max_pictures : (size_t)-1, &b->skipped, n_threads);
     for (const ParsedFrame& f : b->F) {
       if (memcmp(&f.fp, &b->F[0].fp, sizeof(f.fp)) != 0) {
         delete b;
@@ -101,6 +106,50 @@ dryv_h264_batch* dryv_h264_parse_all(const uint8_t* data, size_t n, size_t max_p
   } catch (const Error& e) {
     g_err = e.what;
     return nullptr;
+  }
+}
+/* Parameter sets only: fills fp_out from the stream's first SPS / PPS and returns the number of coded slice NAL units
+ * (an upper bound on the pictures parse_all will deliver); 0 on failure. Cheap: no slice data is decoded. */
+long long dryv_h264_stream_params(const uint8_t* data, size_t n, dryv_frame_params* fp_out) {
+  try {
+    const bool mp4 = n >= 12 && memcmp(data + 4, "ftyp", 4) == 0;
+    const Stream S = mp4 ? demux_mp4(data, n, (size_t)-1) : demux_annexb(data, n);
+    if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
+    if (fp_out) set_flat_params(*fp_out, S.sps.width_mbs, S.sps.height_map_units, S.pps);
+    return (long long)S.slices.size();
+  } catch (const Error& e) {
+    g_err = e.what;
+    return 0;
+  }
+}
+/* The same, with the records and coefficients written straight into the caller's batch buffers (e.g. page-locked memory from
+ * dryv_recon_alloc_host: no intermediate copy), `capacity` pictures large. Returns the number of pictures, 0 on failure;
+ * fp_out / info4 (pictures, skipped slices, all tails ok, reserved) are filled. */
+long long dryv_h264_parse_all_into(const uint8_t* data, size_t n, size_t max_pictures, unsigned n_threads, dryv_mb_desc* mbs_out,
+                                   int16_t* coeffs_out, size_t capacity, dryv_frame_params* fp_out, long long* info4) {
+  try {
+    size_t skipped = 0;
+    const std::vector<ParsedFrame> F = parse_all_islices(data, n, max_pictures ? max_pictures : (size_t)-1, &skipped, n_threads,
+                                                         mbs_out, coeffs_out, capacity);
+    bool tails = true;
+    for (const ParsedFrame& f : F) {
+      if (memcmp(&f.fp, &F[0].fp, sizeof(f.fp)) != 0) {
+        g_err = "pictures of different parameters in one stream";
+        return 0;
+      }
+      tails = tails && f.tail_ok;
+    }
+    if (fp_out) *fp_out = F[0].fp;
+    if (info4) {
+      info4[0] = (long long)F.size();
+      info4[1] = (long long)skipped;
+      info4[2] = tails ? 1 : 0;
+      info4[3] = 0;
+    }
+    return (long long)F.size();
+  } catch (const Error& e) {
+    g_err = e.what;
+    return 0;
   }
 }
 void dryv_h264_batch_free(dryv_h264_batch* b) { delete b; }

@@ -16,7 +16,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dryv_recon.h"
@@ -802,7 +805,10 @@ inline void set_flat_params(dryv_frame_params& fp, int W, int H, const Pps& p) {
 }
 
 // Parses one coded slice NAL unit (header byte included) given the active parameter sets.
-inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, const Pps& p) {
+// mbs_out / co_out: where the picture's records and coefficients go (W * H records, W * H * 384 coefficients, e.g. a
+// slice of a page-locked batch buffer); NULL = into the returned ParsedFrame's own vectors.
+inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, const Pps& p, dryv_mb_desc* mbs_out = nullptr,
+                                    int16_t* co_out = nullptr) {
   if (n < 2) fail("empty NAL unit");
   const int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
   if (type != 5 && type != 1) fail("not a slice NAL unit");
@@ -817,16 +823,22 @@ inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, 
   ParsedFrame F;
   const int W = s.width_mbs, H = s.height_map_units;
   set_flat_params(F.fp, W, H, p);
-  F.mbs.resize((size_t)W * H);
-  F.coeffs.assign((size_t)W * H * 384, 0);
+  if (!mbs_out || !co_out) {
+    F.mbs.resize((size_t)W * H);
+    F.coeffs.assign((size_t)W * H * 384, 0);
+    mbs_out = F.mbs.data();
+    co_out = F.coeffs.data();
+  } else {
+    memset(co_out, 0, (size_t)W * H * 768);
+  }
   F.slice_qp = h.slice_qp;
   for (int k = 0; k < 4; k++) F.crop[k] = 2 * s.crop[k];  // CropUnitX = CropUnitY = 2 for 4:2:0 frame pictures (7.4.2.1.1)
   CabacDecoder cd;
   cd.start(&r, h.slice_qp);
   MbLayer<false, CabacDecoder> L(cd, W, H, p.transform8x8, h.slice_qp);
   for (int a = 0; a < W * H; a++) {
-    L.macroblock(a, F.mbs[a], &F.coeffs[(size_t)a * 384], a == W * H - 1);
-    F.kinds[F.mbs[a].mb_kind]++;
+    L.macroblock(a, mbs_out[a], co_out + (size_t)a * 384, a == W * H - 1);
+    F.kinds[mbs_out[a].mb_kind]++;
   }
   F.bins = cd.bins;
   F.slice_bytes = n;
@@ -846,7 +858,8 @@ struct Stream {
   Sps sps;
   Pps pps;
   bool have_sps = false, have_pps = false;
-  std::vector<std::vector<uint8_t>> slices;  // coded slice NAL units (with header byte), in decoding order
+  struct Nal { const uint8_t* p; size_t n; };
+  std::vector<Nal> slices;  // coded slice NAL units (with header byte) inside the caller's buffer, in decoding order
 };
 
 inline void take_nal(Stream& S, const uint8_t* p, size_t n) {
@@ -859,7 +872,7 @@ inline void take_nal(Stream& S, const uint8_t* p, size_t n) {
     S.pps = parse_pps(unescape(p + 1, n - 1));
     S.have_pps = true;
   } else if (type == 5 || type == 1) {
-    S.slices.emplace_back(p, p + n);
+    S.slices.push_back(Stream::Nal{p, n});
   }
 }
 
@@ -972,19 +985,24 @@ inline Stream demux_mp4(const uint8_t* f, size_t n, size_t max_samples) {
 
 inline Stream demux_annexb(const uint8_t* f, size_t n) {
   Stream S;
-  size_t i = 0, start = (size_t)-1;
+  size_t start = (size_t)-1;
   auto flush = [&](size_t end) {
     if (start == (size_t)-1) return;
     size_t e = end;
     while (e > start && f[e - 1] == 0) e--;  // trailing_zero_8bits
     take_nal(S, f + start, e - start);
   };
-  while (i + 3 <= n) {
-    if (f[i] == 0 && f[i + 1] == 0 && f[i + 2] == 1) {
-      flush(i);
-      start = i + 3;
-      i += 3;
-    } else i++;
+  // start codes 00 00 01: look for the 01 bytes (memchr) and check the two bytes in front
+  size_t i = 2;
+  while (i < n) {
+    const uint8_t* q = (const uint8_t*)memchr(f + i, 1, n - i);
+    if (!q) break;
+    i = (size_t)(q - f);
+    if (f[i - 1] == 0 && f[i - 2] == 0) {
+      flush(i - 2);
+      start = i + 1;
+    }
+    i++;
   }
   flush(n);
   return S;
@@ -995,13 +1013,13 @@ inline ParsedFrame parse_first_islice(const uint8_t* f, size_t n) {
   Stream S = mp4 ? demux_mp4(f, n, 1) : demux_annexb(f, n);
   if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
   if (S.slices.empty()) fail("no coded slice");
-  return parse_islice_nal(S.slices[0].data(), S.slices[0].size(), S.sps, S.pps);
+  return parse_islice_nal(S.slices[0].p, S.slices[0].n, S.sps, S.pps);
 }
 
 // Whether a coded slice NAL unit starts a picture that consists of one I slice (what this parser decodes).
-inline bool is_whole_picture_islice(const std::vector<uint8_t>& nal) {
-  if (nal.size() < 2) return false;
-  const std::vector<uint8_t> rbsp = unescape(nal.data() + 1, std::min<size_t>(nal.size() - 1, 16));
+inline bool is_whole_picture_islice(const uint8_t* nal, size_t n) {
+  if (n < 2) return false;
+  const std::vector<uint8_t> rbsp = unescape(nal + 1, std::min<size_t>(n - 1, 16));
   BitReader r{rbsp.data(), rbsp.size(), 0};
   try {
     const unsigned first_mb = r.ue(), type = r.ue();
@@ -1014,22 +1032,57 @@ inline bool is_whole_picture_islice(const std::vector<uint8_t>& nal) {
 // Every picture of the stream that is a single I slice, up to max_pictures (the reference stops after sample 0:
 // decoder.rs:88, quirk Q9 -- a batch of pictures is this build's own unit of work), all under the stream's first SPS /
 // PPS. Inter pictures in between are skipped; their count is returned in *skipped.
-inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, size_t max_pictures, size_t* skipped = nullptr) {
+// n_threads: intra pictures are independent of each other (CABAC contexts and the QP predictor restart with every slice:
+// cabac/mod.rs:72-87, slice/mod.rs:153), so their macroblock layers are parsed in parallel; 0 = one thread per hardware
+// thread (at most one per picture).
+// mbs_out / co_out (optional): one batch buffer for all pictures, `capacity` pictures large; the returned ParsedFrames
+// then carry only parameters and diagnostics.
+inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, size_t max_pictures, size_t* skipped = nullptr,
+                                                  unsigned n_threads = 1, dryv_mb_desc* mbs_out = nullptr,
+                                                  int16_t* co_out = nullptr, size_t capacity = 0) {
   const bool mp4 = n >= 12 && memcmp(f + 4, "ftyp", 4) == 0;
   Stream S = mp4 ? demux_mp4(f, n, (size_t)-1) : demux_annexb(f, n);
   if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
-  std::vector<ParsedFrame> out;
+  std::vector<Stream::Nal> todo;
   size_t skip = 0;
-  for (const std::vector<uint8_t>& nal : S.slices) {
-    if (out.size() >= max_pictures) break;
-    if (!is_whole_picture_islice(nal)) {
+  for (const Stream::Nal& nal : S.slices) {
+    if (todo.size() >= max_pictures) break;
+    if (!is_whole_picture_islice(nal.p, nal.n)) {
       skip++;
       continue;
     }
-    out.push_back(parse_islice_nal(nal.data(), nal.size(), S.sps, S.pps));
+    todo.push_back(nal);
   }
   if (skipped) *skipped = skip;
-  if (out.empty()) fail("no intra picture");
+  if (todo.empty()) fail("no intra picture");
+  const size_t perPic = (size_t)S.sps.width_mbs * S.sps.height_map_units;
+  if (mbs_out && co_out && todo.size() > capacity) fail("batch buffer too small");
+  auto parse_one = [&](size_t k) {
+    return parse_islice_nal(todo[k].p, todo[k].n, S.sps, S.pps, mbs_out && co_out ? mbs_out + k * perPic : nullptr,
+                            mbs_out && co_out ? co_out + k * perPic * 384 : nullptr);
+  };
+  std::vector<ParsedFrame> out(todo.size());
+  if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+  n_threads = (unsigned)std::min<size_t>(n_threads, todo.size());
+  if (n_threads <= 1) {
+    for (size_t k = 0; k < todo.size(); k++) out[k] = parse_one(k);
+    return out;
+  }
+  std::atomic<size_t> next{0};
+  std::vector<std::string> errs(n_threads);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < n_threads; t++)
+    pool.emplace_back([&, t]() {
+      try {
+        for (size_t k = next++; k < todo.size(); k = next++) out[k] = parse_one(k);
+      } catch (const Error& e) {
+        errs[t] = e.what.empty() ? "parse error" : e.what;
+        next = todo.size();
+      }
+    });
+  for (std::thread& th : pool) th.join();
+  for (const std::string& e : errs)
+    if (!e.empty()) fail(e.c_str());
   return out;
 }
 
@@ -1099,7 +1152,10 @@ inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const
     w.trailing();
     append_nal_annexb(out, 0x68, w.out);
   }
-  for (int pic = 0; pic < n_pictures; pic++, mbs += W * H, coeffs += (size_t)W * H * 384) {
+  std::vector<std::vector<uint8_t>> slices((size_t)n_pictures);
+  auto encode_picture = [&](int pic) {
+    const dryv_mb_desc* pm = mbs + (size_t)pic * W * H;
+    const int16_t* pc = coeffs + (size_t)pic * W * H * 384;
     BitWriter w;  // slice header (7.3.3), IDR, I slice
     w.ue(0);
     w.ue(7);
@@ -1115,13 +1171,35 @@ inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const
     MbLayer<true, CabacEncoder> L(ce, W, H, fp.transform_8x8_mode_flag != 0, slice_qp);
     std::vector<int16_t> co(384);
     for (int a = 0; a < W * H; a++) {
-      dryv_mb_desc d = mbs[a];
-      memcpy(co.data(), coeffs + (size_t)a * 384, 768);
+      dryv_mb_desc d = pm[a];
+      memcpy(co.data(), pc + (size_t)a * 384, 768);
       L.macroblock(a, d, co.data(), a == W * H - 1);
     }
     while (w.nbits & 7) w.bit(0);
-    append_nal_annexb(out, 0x65, w.out);
+    append_nal_annexb(slices[(size_t)pic], 0x65, w.out);
+  };
+  // pictures are independent: encode them on all hardware threads, then append in order
+  const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), (size_t)n_pictures);
+  if (nt <= 1) {
+    for (int pic = 0; pic < n_pictures; pic++) encode_picture(pic);
+  } else {
+    std::atomic<int> next{0};
+    std::vector<std::string> errs(nt);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t++)
+      pool.emplace_back([&, t]() {
+        try {
+          for (int pic = next++; pic < n_pictures; pic = next++) encode_picture(pic);
+        } catch (const Error& e) {
+          errs[t] = e.what.empty() ? "encode error" : e.what;
+          next = n_pictures;
+        }
+      });
+    for (std::thread& th : pool) th.join();
+    for (const std::string& e : errs)
+      if (!e.empty()) fail(e.c_str());
   }
+  for (const std::vector<uint8_t>& sl : slices) out.insert(out.end(), sl.begin(), sl.end());
   return out;
 }
 

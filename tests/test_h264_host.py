@@ -149,3 +149,22 @@ def test_real_mp4_intra_pictures_among_inter_ones():
     assert bytes(fp) == bytes(fp1) and np.array_equal(co[:300], co1) and np.array_equal(mbs[:300], mbs1)
     st, yuv = oracle.reconstruct(fp, n_pic, mbs, co)
     assert st == 0
+
+
+def test_parse_into_batch_buffers_in_parallel():
+    """stream_params sizes the buffers from the parameter sets alone; parse_all_islices_into then parses the pictures on
+    several threads straight into the caller's batch arrays: same result as the copying, single-threaded entry point."""
+    fp = abi.make_frame_params(10, 6, transform_8x8=True)
+    frames = 7
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3), 99, 0, frames)
+    stream = h264.encode_stream(fp, frames, mbs, co, slice_qp=int(mbs["qp"][0]))
+    fps, n_slices = h264.stream_params(stream)
+    assert bytes(fps) == bytes(fp) and n_slices == frames
+    per = 60
+    m_out = np.zeros(n_slices * per, dtype=abi.MB_DESC_DTYPE)
+    c_out = np.full((n_slices * per, 384), 77, dtype=np.int16)      # (must be cleared by the parser)
+    fp2, n2, info = h264.parse_all_islices_into(stream, m_out, c_out, threads=4)
+    ref = h264.parse_all_islices(stream)
+    assert n2 == frames and info["tails_ok"] == 1 and np.array_equal(c_out, ref[3]) and np.array_equal(m_out, ref[2])
+    with pytest.raises(h264.H264Error):                              # too small a buffer is refused, not overrun
+        h264.parse_all_islices_into(stream, m_out[:3 * per], c_out[:3 * per], threads=2)
