@@ -61,6 +61,18 @@ class OutputDesc(C.Structure):
 OUT_I420, OUT_NV12 = 0, 1
 
 
+class DeblockParams(C.Structure):
+    """dryv_deblock_params (4 bytes): the slice header's deblocking syntax elements."""
+    _fields_ = [("disable_deblocking_filter_idc", C.c_uint8), ("slice_alpha_c0_offset_div2", C.c_int8),
+                ("slice_beta_offset_div2", C.c_int8), ("reserved", C.c_uint8)]
+
+
+def make_deblock_params(disable_idc=0, alpha_div2=0, beta_div2=0):
+    dp = DeblockParams()
+    dp.disable_deblocking_filter_idc, dp.slice_alpha_c0_offset_div2, dp.slice_beta_offset_div2 = disable_idc, alpha_div2, beta_div2
+    return dp
+
+
 def make_output_desc(fmt=OUT_I420, crop=(0, 0, 0, 0)):
     od = OutputDesc()
     od.format = fmt
@@ -94,6 +106,8 @@ SYMBOLS = {
     "dryv_recon_pack_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.POINTER(OutputDesc),
                                          C.c_void_p]),
     "dryv_recon_wait_packed": (C.c_int, [C.c_void_p, C.POINTER(OutputDesc), C.c_void_p, C.c_size_t]),
+    "dryv_recon_deblock_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.POINTER(DeblockParams), C.c_uint32, C.c_void_p,
+                                            C.c_void_p]),
     "dryv_recon_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "dryv_recon_stream": (C.c_void_p, [C.c_void_p]),
     "dryv_recon_strerror": (C.c_char_p, [C.c_int]),

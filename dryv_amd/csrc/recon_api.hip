@@ -16,6 +16,8 @@
 #include "recon_kernel.h"
 #include "recon_params.h"
 #include "output_pack.h"
+#include "deblock_launch.h"
+#include "deblock_params.h"
 
 using dryv::KParams;
 using dryv::params::build_params;
@@ -32,6 +34,8 @@ struct dryv_recon_ctx {
   void* d_yuv = nullptr;
   size_t cap_mbs = 0, cap_coeffs = 0, cap_yuv = 0;
   void* d_pack = nullptr;        // output stage (dryv_recon_wait_packed): grow-only
+  void* d_dbwork = nullptr;      // deblocking workspace (task counter, progress words, side buffer): grow-only
+  size_t cap_dbwork = 0;
   size_t cap_pack = 0;
   dryv_frame_params pending_fp;  // the parameters of the host-path batch in flight
   uint32_t pending_frames = 0;
@@ -60,6 +64,7 @@ struct dryv_recon_ctx {
   const dryv_mb_desc* piped_mbs = nullptr;
   const int16_t* piped_coeffs = nullptr;
   uint8_t* piped_out = nullptr;
+  bool deblock_pending = false;  // a deblocking launch has not been synchronised yet (its status word is unread)
   std::string last_error;
 };
 
@@ -271,6 +276,7 @@ void dryv_recon_destroy(dryv_recon_ctx* ctx) {
   if (ctx->d_coeffs) (void)hipFree(ctx->d_coeffs);
   if (ctx->d_yuv) (void)hipFree(ctx->d_yuv);
   if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+  if (ctx->d_dbwork) (void)hipFree(ctx->d_dbwork);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -373,6 +379,37 @@ int dryv_recon_wait_packed(dryv_recon_ctx* ctx, const dryv_output_desc* od, uint
   return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;
 }
 
+/* ---- in-loop deblocking filter ---------------------------------------------------------------------- */
+int dryv_recon_deblock_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, const dryv_deblock_params* dp, uint32_t n_frames,
+                              const void* d_mbs, void* d_yuv) {
+  if (!ctx || !d_mbs || !d_yuv) return DRYV_E_INVALID;
+  if (((uintptr_t)d_mbs | (uintptr_t)d_yuv) & 15u) return DRYV_E_INVALID;
+  if (ctx->in_flight) return DRYV_E_STATE;  // (the pictures are final only after the batch's sync: see dryv_recon_pack_device)
+  dryv::deblock::DParams P;
+  int skip = 0;
+  int st = dryv::deblock::build_dparams(fp, dp, n_frames, &P, &skip);
+  if (st != DRYV_OK) return st;
+  if (skip) return DRYV_OK;  // disable_deblocking_filter_idc = 1
+  (void)hipSetDevice(ctx->device);
+  if ((st = ensure(ctx, &ctx->d_dbwork, &ctx->cap_dbwork, dryv::deblock::workspace_bytes(P))) != DRYV_OK) return st;
+  hipError_t e = hipMemsetAsync(ctx->d_dbwork, 0, dryv::deblock::reset_bytes(P), ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(deblock workspace)");
+  const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
+  const int wpb = dryv::deblock_waves_per_block();
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::deblock_blocks_per_cu();
+  grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
+  if ((e = hipEventRecord(ctx->ev_start, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  if ((e = dryv::deblock_launch(P, d_mbs, d_yuv, ctx->d_status, ctx->d_dbwork, (int)grid, ctx->stream)) != hipSuccess)
+    return fail(ctx, e, "deblock_kernel launch");
+  if ((e = hipEventRecord(ctx->ev_stop, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
+  if ((e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+    return fail(ctx, e, "hipMemcpyAsync(status)");
+  ctx->timed = true;
+  ctx->deblock_pending = true;
+  return DRYV_OK;
+}
+
 /* ---- pinned host memory + pipelined host-buffer path ---------------------------------------------- */
 void* dryv_recon_alloc_host(size_t bytes) {
   void* p = nullptr;
@@ -470,7 +507,18 @@ int dryv_recon_sync(dryv_recon_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (!ctx->in_flight) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    return e == hipSuccess ? DRYV_OK : fail(ctx, e, "hipStreamSynchronize");
+    if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
+    if (ctx->deblock_pending) {
+      ctx->deblock_pending = false;
+      if (*ctx->h_status & 4u) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "deblock kernel: band task %u gave up waiting at step %u for the band above (saw %u macroblocks)",
+                 ctx->h_status[1], ctx->h_status[2] >> 16, ctx->h_status[3]);
+        ctx->last_error = msg;
+        return DRYV_E_DEVICE;
+      }
+    }
+    return DRYV_OK;
   }
   const int st = finish(ctx);
   if (!ctx->in_flight_host) ctx->in_flight = false;

@@ -110,6 +110,11 @@ class ReconContext:
         _check(self._lib.dryv_recon_pack_device(self._h, C.byref(fp), int(n_frames), C.c_void_p(d_yuv), C.byref(od),
                                                 C.c_void_p(d_out)), self._h)
 
+    def deblock_device(self, fp, dp, n_frames, d_mbs, d_yuv):
+        """dryv_recon_deblock_device: H.264 8.7 on reconstructed pictures in device memory, in place; completes at sync()."""
+        _check(self._lib.dryv_recon_deblock_device(self._h, C.byref(fp), C.byref(dp), int(n_frames), C.c_void_p(d_mbs),
+                                                   C.c_void_p(d_yuv)), self._h)
+
     def reconstruct(self, fp, n_frames, mbs, coeffs, allow_unsupported=False):
         self.submit(fp, n_frames, mbs, coeffs)
         return self.wait(allow_unsupported=allow_unsupported)

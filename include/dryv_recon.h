@@ -157,6 +157,21 @@ int dryv_recon_pack_device(dryv_recon_ctx *ctx, const dryv_frame_params *fp, uin
  * it on the device and copies n_frames * dryv_recon_output_bytes() bytes into out. */
 int dryv_recon_wait_packed(dryv_recon_ctx *ctx, const dryv_output_desc *od, uint8_t *out, size_t out_bytes);
 
+/* ---- in-loop deblocking filter ---------------------------------------------------------------------------
+ * ITU-T H.264 clause 8.7 for this library's domain (frame macroblocks, 4:2:0, 8 bit, one slice per picture, all macroblocks
+ * intra). dryv parses the syntax elements below (slice/header.rs:609-640) and does not filter (README.md:15 unchecked): there
+ * is no reference behaviour to be equal to, and reconstruction's default output stays unfiltered, as dryv's is. */
+typedef struct {
+  uint8_t disable_deblocking_filter_idc; /* 0 filter every edge, 1 none, 2 = 0 for one slice per picture */
+  int8_t slice_alpha_c0_offset_div2;     /* -6..6 */
+  int8_t slice_beta_offset_div2;         /* -6..6 */
+  uint8_t reserved;
+} dryv_deblock_params;
+/* Filters n_frames reconstructed pictures at d_yuv in place; d_mbs: the batch's records in device memory (qp and kind are
+ * read). Asynchronous on the context's stream; pair with dryv_recon_sync. DRYV_E_STATE while a batch is in flight. */
+int dryv_recon_deblock_device(dryv_recon_ctx *ctx, const dryv_frame_params *fp, const dryv_deblock_params *dp,
+                              uint32_t n_frames, const void *d_mbs, void *d_yuv);
+
 /* Device time of the most recent reconstruction kernel launch, from HIP events recorded on the
  * context's own stream immediately around the launch. Valid after wait/sync. */
 int dryv_recon_last_kernel_ms(dryv_recon_ctx *ctx, float *ms);

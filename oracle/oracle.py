@@ -11,10 +11,9 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(HERE, "dryv_oracle.c")
-    hdr = os.path.join(HERE, "..", "include", "dryv_recon.h")
-    stale = (not os.path.exists(SO) or os.path.getmtime(src) > os.path.getmtime(SO)
-             or os.path.getmtime(hdr) > os.path.getmtime(SO))
+    deps = [os.path.join(HERE, "dryv_oracle.c"), os.path.join(HERE, "dryv_deblock.c"),
+            os.path.join(HERE, "..", "include", "dryv_recon.h")]
+    stale = not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps)
     if force or stale:
         r = subprocess.run(["make", "-C", HERE] + (["-B"] if force else []), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True)
@@ -38,6 +37,8 @@ def load():
                                                  C.c_void_p]
         _lib.dryv_oracle_residual8x8.restype = None
         _lib.dryv_oracle_residual8x8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.dryv_oracle_deblock.restype = C.c_int
+        _lib.dryv_oracle_deblock.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.dryv_oracle_get_qpc.restype = C.c_int64
         _lib.dryv_oracle_get_qpc.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _lib.dryv_oracle_clamp.restype = C.c_int64
@@ -95,3 +96,13 @@ def residual8x8(fp, qp, c):
 
 def get_qpc(fp, qpy, is_chroma_cb):
     return int(load().dryv_oracle_get_qpc(C.addressof(fp), qpy, int(is_chroma_cb)))
+
+
+def deblock(fp, dp, n_frames, mbs, yuv):
+    """H.264 8.7 on reconstructed pictures (oracle/dryv_deblock.c). dp: dryv_amd.abi.DeblockParams. Returns (status, filtered copy)."""
+    mbs = np.ascontiguousarray(mbs)
+    out = np.array(yuv, dtype=np.uint8, copy=True)
+    n_mbs = n_frames * fp.pic_width_in_mbs * fp.pic_height_in_mbs
+    assert mbs.size == n_mbs and out.size == n_mbs * 384
+    st = load().dryv_oracle_deblock(C.addressof(fp), C.addressof(dp), n_frames, mbs.ctypes.data, out.ctypes.data)
+    return st, out

@@ -184,3 +184,62 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
   if (status_out) *status_out = status[0] & ~2u;
   return DRYV_OK;
 }
+
+// ---- the deblocking kernel (dryv_amd/csrc/deblock_kernel.h) under the same emulator ---------------------------------------
+#include "../../dryv_amd/csrc/deblock_kernel.h"
+#include "../../dryv_amd/csrc/deblock_params.h"
+
+static dryv::deblock::DParams g_DP;
+static dryv::deblock::Args g_DA;
+static void deblock_body() { dryv::deblock::deblock_wave(g_DP, g_DA, 0, dryv::deblock::T_END); }
+
+// n_waves independent band waves (each with its own LDS), scheduled round-robin from `first`, `order` = +1 / -1.
+extern "C" int dryv_emu_deblock(const dryv_frame_params* fp, const dryv_deblock_params* dp, uint32_t n_frames, const dryv_mb_desc* mbs,
+                                uint8_t* yuv, unsigned* status_out, int n_waves, int first, int order) {
+  int skip = 0;
+  int st = dryv::deblock::build_dparams(fp, dp, n_frames, &g_DP, &skip);
+  if (st != DRYV_OK) return st;
+  if (status_out) *status_out = 0;
+  if (skip) return DRYV_OK;
+  if (n_waves < 1) n_waves = 1;
+  std::vector<uint8_t> ws(dryv::deblock::workspace_bytes(g_DP), 0xC3);
+  memset(ws.data(), 0, dryv::deblock::reset_bytes(g_DP));
+  unsigned status[4] = {0, 0, 0, 0};
+  g_DA = dryv::deblock::Args{mbs, yuv, status, (unsigned*)ws.data(), (unsigned*)(ws.data() + 256),
+                             ws.data() + dryv::deblock::reset_bytes(g_DP)};
+  wv::g_body = deblock_body;
+  const int ldsBytes = dryv::deblock::T_END + dryv::deblock::S_BYTES;
+  std::vector<std::unique_ptr<wv::Wave>> waves;
+  std::vector<std::vector<uint8_t>> lds(n_waves, std::vector<uint8_t>(ldsBytes, 0xA5));
+  for (int w = 0; w < n_waves; w++) {
+    waves.emplace_back(new wv::Wave());
+    waves.back()->index = w;
+    waves.back()->st.lds = lds[w].data();
+    waves.back()->st.lds_bytes = ldsBytes;
+    wv::init_wave(waves.back().get());
+    wv::g_emu_cur = &waves.back()->st;
+    dryv::deblock::build_tables(g_DP, 0, 0, 1);
+  }
+  const size_t nProg = (size_t)n_frames * ((g_DP.H + 3) / 4);
+  int live = n_waves;
+  unsigned long long idle_rounds = 0;
+  for (int k = 0; live > 0; k++) {
+    wv::Wave* w = waves[(((first + order * k) % n_waves) + n_waves) % n_waves].get();
+    if (w->finished) continue;
+    auto progress = [&]() {
+      unsigned long long t = *g_DA.taskCounter;
+      for (size_t q = 0; q < nProg; q++) t += g_DA.prog[q];
+      return t;
+    };
+    const unsigned long long before = progress();
+    const int r = wv::run_slice(w);
+    if (r == 2) live--;
+    if (r == 2 || progress() != before) idle_rounds = 0;
+    else if (++idle_rounds > (unsigned long long)n_waves * 64) {
+      fprintf(stderr, "emu: deblock deadlock: %d waves are polling and nothing makes progress\n", live);
+      abort();
+    }
+  }
+  if (status_out) *status_out = status[0];
+  return DRYV_OK;
+}

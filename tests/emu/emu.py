@@ -16,7 +16,8 @@ def build(force=False, defs=()):
     SO = os.path.join(HERE, "libdryv_emu%s.so" % "".join("_" + d.replace("-D", "").replace("=", "") for d in defs))
     csrc = os.path.join(HERE, "..", "..", "dryv_amd", "csrc")
     deps = [os.path.join(HERE, "band_emu.cpp")] + [os.path.join(csrc, f) for f in
-                                                    ("band_kernel.h", "wave.h", "kparams.h", "recon_params.h")]
+                                                    ("band_kernel.h", "wave.h", "kparams.h", "recon_params.h", "deblock_kernel.h",
+                                                     "deblock_kernel_params.h", "deblock_params.h")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         r = subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DDRYV_EMU", "-Wall",
                             "-Wno-unused-function", *defs, "-o", SO, deps[0]], stdout=subprocess.PIPE,
@@ -45,3 +46,23 @@ def reconstruct(fp, n_frames, mbs, coeffs, n_teams=1, first=0, order=1, defs=())
                                    C.addressof(status), n_teams, first, order)
     assert st == 0, st
     return int(status.value), yuv
+
+
+def deblock(fp, dp, n_frames, mbs, yuv, n_waves=1, first=0, order=1):
+    """The deblocking kernel's source (dryv_amd/csrc/deblock_kernel.h) under the lane emulator. Returns (status, filtered copy)."""
+    if () not in _libs:
+        lib = C.CDLL(build())
+        lib.dryv_emu_reconstruct.restype = C.c_int
+        lib.dryv_emu_reconstruct.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int]
+        _libs[()] = lib
+    lib = _libs[()]
+    lib.dryv_emu_deblock.restype = C.c_int
+    lib.dryv_emu_deblock.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    mbs = np.ascontiguousarray(mbs)
+    out = np.array(yuv, dtype=np.uint8, copy=True)
+    status = C.c_uint(0)
+    st = lib.dryv_emu_deblock(C.addressof(fp), C.addressof(dp), n_frames, mbs.ctypes.data, out.ctypes.data, C.addressof(status),
+                              n_waves, first, order)
+    assert st == 0, st
+    return int(status.value), out

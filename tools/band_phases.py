@@ -29,7 +29,7 @@ PHASES = {
 def main():
     frame_list = [int(a) for a in sys.argv[1:]] or [1, 300]
     so = os.path.join(_build.LIB, "libdryv_recon_bprof.so")
-    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "recon_api.hip")]
+    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
     subprocess.check_call([_build.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-DDRYV_BAND_PROFILE", "-o", so] + srcs)
     import torch

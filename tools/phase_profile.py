@@ -24,7 +24,7 @@ PHASES = ["claim", "record/consts", "wait vmcnt(0)", "residuals", "poll row abov
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     so = os.path.join(_build.LIB, "libdryv_recon_prof.so")
-    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "recon_api.hip")]
+    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
     subprocess.check_call([_build.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-DDRYV_PHASE_PROFILE", "-o", so] + srcs)
     import torch

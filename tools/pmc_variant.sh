@@ -14,7 +14,7 @@ for v in "$@"; do
   if [ "$v" != base ]; then
     so=$R/dryv_amd/lib/libdryv_recon_pv$i.so
     defs=$(echo $v | sed 's/+/ -D/g; s/^/-D/')
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $defs -o $so $R/dryv_amd/csrc/recon_kernel.hip $R/dryv_amd/csrc/recon_band.hip $R/dryv_amd/csrc/output_pack.hip $R/dryv_amd/csrc/recon_api.hip
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $defs -o $so $R/dryv_amd/csrc/recon_kernel.hip $R/dryv_amd/csrc/recon_band.hip $R/dryv_amd/csrc/output_pack.hip $R/dryv_amd/csrc/deblock.hip $R/dryv_amd/csrc/recon_api.hip
   fi
   (cd /tmp && export TMPDIR=/tmp && DRYV_RECON_LIB=$so rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/v$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/v$i.log 2>&1) || echo "failed: $v"
   python3 - $OUT/v$i "$v" <<'PY'

@@ -29,7 +29,7 @@ def main():
     frames = [int(x) for x in a.frames.split(",")]
     grids = [int(x) for x in a.grid.split(",")]
     import torch
-    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "recon_api.hip")]
+    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
     fp, mbs, co, _ = synth.workload(a.workload, n_frames=max(frames))
     per = fp.pic_width_in_mbs * fp.pic_height_in_mbs
     d_m = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda()
