@@ -106,6 +106,7 @@ SYMBOLS = {
     "dryv_recon_pack_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.POINTER(OutputDesc),
                                          C.c_void_p]),
     "dryv_recon_wait_packed": (C.c_int, [C.c_void_p, C.POINTER(OutputDesc), C.c_void_p, C.c_size_t]),
+    "dryv_recon_wait_filtered": (C.c_int, [C.c_void_p, C.POINTER(DeblockParams), C.POINTER(OutputDesc), C.c_void_p, C.c_size_t]),
     "dryv_recon_deblock_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.POINTER(DeblockParams), C.c_uint32, C.c_void_p,
                                             C.c_void_p]),
     "dryv_recon_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -356,27 +356,7 @@ int dryv_recon_pack_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uin
 }
 
 int dryv_recon_wait_packed(dryv_recon_ctx* ctx, const dryv_output_desc* od, uint8_t* out, size_t out_bytes) {
-  if (!ctx || !od || !out) return DRYV_E_INVALID;
-  if (!ctx->in_flight || !ctx->in_flight_host) return DRYV_E_STATE;
-  dryv::PackGeo G;
-  int st = dryv::pack_geometry(&ctx->pending_fp, od, ctx->pending_frames, &G);
-  if (st != DRYV_OK) return st;  // (the batch stays in flight: dryv_recon_wait can still fetch it)
-  const size_t need = G.dst_frame_bytes * ctx->pending_frames;
-  if (out_bytes < need) return DRYV_E_INVALID;
-  (void)hipSetDevice(ctx->device);
-  if ((st = ensure(ctx, &ctx->d_pack, &ctx->cap_pack, need)) != DRYV_OK) return st;
-  st = finish(ctx);
-  hipError_t e = hipSuccess;
-  if (st == DRYV_OK) {
-    e = dryv::pack_launch(G, ctx->d_yuv, ctx->d_pack, ctx->num_cus, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, ctx->d_pack, need, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  }
-  ctx->in_flight = false;
-  ctx->in_flight_host = false;
-  if (st != DRYV_OK) return st;
-  if (e != hipSuccess) return fail(ctx, e, "pack / D2H");
-  return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;
+  return dryv_recon_wait_filtered(ctx, nullptr, od, out, out_bytes);
 }
 
 /* ---- in-loop deblocking filter ---------------------------------------------------------------------- */
@@ -408,6 +388,44 @@ int dryv_recon_deblock_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, 
   ctx->timed = true;
   ctx->deblock_pending = true;
   return DRYV_OK;
+}
+
+/* dryv_recon_wait with the stages behind reconstruction: deblocking (dp, may be NULL) and cropping / packing (od, may be NULL) */
+int dryv_recon_wait_filtered(dryv_recon_ctx* ctx, const dryv_deblock_params* dp, const dryv_output_desc* od, uint8_t* out,
+                             size_t out_bytes) {
+  if (!ctx || !out) return DRYV_E_INVALID;
+  if (!ctx->in_flight || !ctx->in_flight_host) return DRYV_E_STATE;
+  static const dryv_output_desc plain = {DRYV_OUT_I420, {0, 0, 0}, 0, 0, 0, 0};
+  dryv::PackGeo G;
+  int st = dryv::pack_geometry(&ctx->pending_fp, od ? od : &plain, ctx->pending_frames, &G);
+  if (st != DRYV_OK) return st;  // (the batch stays in flight: dryv_recon_wait can still fetch it)
+  dryv::deblock::DParams DP;
+  int skip = 1;
+  if (dp && (st = dryv::deblock::build_dparams(&ctx->pending_fp, dp, ctx->pending_frames, &DP, &skip)) != DRYV_OK) return st;
+  const size_t need = G.dst_frame_bytes * ctx->pending_frames;
+  if (out_bytes < need) return DRYV_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  if (od && (st = ensure(ctx, &ctx->d_pack, &ctx->cap_pack, need)) != DRYV_OK) return st;
+  st = finish(ctx);
+  const bool unsupported = st == DRYV_OK && (*ctx->h_status & 1u);
+  ctx->in_flight = false;
+  ctx->in_flight_host = false;
+  if (st != DRYV_OK) return st;
+  if (dp && !skip) {
+    const dryv_frame_params fp = ctx->pending_fp;
+    if ((st = dryv_recon_deblock_device(ctx, &fp, dp, ctx->pending_frames, ctx->d_mbs, ctx->d_yuv)) != DRYV_OK) return st;
+    if ((st = dryv_recon_sync(ctx)) != DRYV_OK) return st;
+  }
+  hipError_t e = hipSuccess;
+  const void* src = ctx->d_yuv;
+  if (od) {
+    e = dryv::pack_launch(G, ctx->d_yuv, ctx->d_pack, ctx->num_cus, ctx->stream);
+    src = ctx->d_pack;
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, src, need, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "filter / pack / D2H");
+  return unsupported ? DRYV_E_UNSUPPORTED : DRYV_OK;
 }
 
 /* ---- pinned host memory + pipelined host-buffer path ---------------------------------------------- */

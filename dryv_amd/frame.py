@@ -105,6 +105,19 @@ class ReconContext:
         self.last_status = st
         return out
 
+    def wait_filtered(self, dp=None, od=None):
+        """dryv_recon_wait_filtered: the batch submitted with submit(), deblocked (dp) and / or cropped / packed (od)."""
+        mbs, coeffs, fp = self._keep
+        n_frames = mbs.size // (fp.pic_width_in_mbs * fp.pic_height_in_mbs)
+        per = self._lib.dryv_recon_output_bytes(C.byref(fp), C.byref(od)) if od is not None else self._lib.dryv_recon_frame_bytes(C.byref(fp))
+        out = np.empty(per * n_frames, dtype=np.uint8)
+        st = self._lib.dryv_recon_wait_filtered(self._h, C.byref(dp) if dp is not None else None,
+                                                C.byref(od) if od is not None else None, out.ctypes.data, out.size)
+        self._keep = None
+        _check(st, self._h)
+        self.last_status = st
+        return out
+
     def pack_device(self, fp, n_frames, d_yuv, od, d_out):
         """dryv_recon_pack_device on raw device pointers; completes at sync()."""
         _check(self._lib.dryv_recon_pack_device(self._h, C.byref(fp), int(n_frames), C.c_void_p(d_yuv), C.byref(od),

@@ -39,6 +39,7 @@ def _load():
         _lib.dryv_h264_encode_idr_cropped.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                       C.c_size_t]
         _lib.dryv_h264_crop.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.dryv_h264_deblock_params.argtypes = [C.c_void_p, C.c_void_p]
         _lib.dryv_h264_parse_all.restype = C.c_void_p
         _lib.dryv_h264_parse_all.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         _lib.dryv_h264_stream_params.restype = C.c_longlong
@@ -83,11 +84,14 @@ def parse_first_islice(data):
         lib.dryv_h264_info(h, info.ctypes.data)
         crop = np.zeros(4, dtype=np.int32)
         lib.dryv_h264_crop(h, crop.ctypes.data)
+        dbp = abi.DeblockParams()
+        lib.dryv_h264_deblock_params(h, C.addressof(dbp))
     finally:
         lib.dryv_h264_free(h)
     keys = ("bins", "slice_bytes", "bits_unread", "tail_ok", "n_i4x4", "n_i8x8", "n_i16x16", "slice_qp")
     d = dict(zip(keys, (int(v) for v in info)))
     d["crop"] = tuple(int(v) for v in crop)   # luma samples: left, right, top, bottom (sps.rs:252-267)
+    d["deblock"] = dbp                        # the slice header's deblocking syntax elements (header.rs:609-640)
     return fp, mbs, coeffs, d
 
 

@@ -131,8 +131,46 @@ static int decode_all(const char* in, const char* outp) {
   return 0;
 }
 
+// frame_harness decode-deblocked <in.mp4 | in.h264> <out.yuv>: the first intra picture, reconstructed AND deblocked with the
+// slice header's own deblocking syntax elements (h264_islice.hpp: ParsedFrame::deblock): what a conformant decoder outputs
+// for that picture -- beyond dryv, which parses those elements and does not filter (README.md:15).
+static int decode_deblocked(const char* in, const char* outp) {
+  FILE* f = std::fopen(in, "rb");
+  if (!f) { std::perror("open"); return 2; }
+  std::vector<uint8_t> data;
+  uint8_t buf[65536];
+  size_t k;
+  while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
+  std::fclose(f);
+  dryv::h264::ParsedFrame P;
+  try {
+    P = dryv::h264::parse_first_islice(data.data(), data.size());
+  } catch (const dryv::h264::Error& e) {
+    std::fprintf(stderr, "parse: %s\n", e.what.c_str());
+    return 6;
+  }
+  if (!P.tail_ok) return 6;
+  std::printf("parsed %ux%u macroblocks; deblocking: disable_idc %d, alpha offset %d, beta offset %d\n", P.fp.pic_width_in_mbs,
+              P.fp.pic_height_in_mbs, P.deblock.disable_deblocking_filter_idc, 2 * P.deblock.slice_alpha_c0_offset_div2,
+              2 * P.deblock.slice_beta_offset_div2);
+  dryv_recon_ctx* ctx = nullptr;
+  int st = dryv_recon_create(&ctx, 0);
+  if (st != DRYV_OK) { std::fprintf(stderr, "dryv_recon_create: %s\n", dryv_recon_strerror(st)); return 3; }
+  std::vector<uint8_t> yuv(dryv_recon_frame_bytes(&P.fp));
+  st = dryv_recon_submit(ctx, &P.fp, 1, P.mbs.data(), P.coeffs.data());
+  if (st == DRYV_OK) st = dryv_recon_wait_filtered(ctx, &P.deblock, nullptr, yuv.data(), yuv.size());
+  if (st != DRYV_OK) { std::fprintf(stderr, "reconstruct / deblock: %s\n", dryv_recon_strerror(st)); return 5; }
+  FILE* out = std::fopen(outp, "wb");
+  if (!out) return 2;
+  std::fwrite(yuv.data(), 1, yuv.size(), out);
+  std::fclose(out);
+  dryv_recon_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 4 && std::strcmp(argv[1], "decode") == 0) return decode_file(argv[2], argv[3]);
+  if (argc == 4 && std::strcmp(argv[1], "decode-deblocked") == 0) return decode_deblocked(argv[2], argv[3]);
   if (argc == 4 && std::strcmp(argv[1], "decode-all") == 0) return decode_all(argv[2], argv[3]);
   if (argc != 3) { std::fprintf(stderr, "usage: %s in.batch out.yuv\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");

@@ -47,6 +47,9 @@ void dryv_h264_crop(const dryv_h264_frame* h, int* crop4) {
   for (int k = 0; k < 4; k++) crop4[k] = h->F.crop[k];
 }
 
+/* The slice header's deblocking syntax elements (disable_deblocking_filter_idc, slice_alpha_c0_offset_div2, slice_beta_offset_div2). */
+void dryv_h264_deblock_params(const dryv_h264_frame* h, dryv_deblock_params* out) { *out = h->F.deblock; }
+
 /* Encodes one picture (flat scaling lists) as an Annex-B stream: SPS, PPS, one IDR I slice. Returns the byte count, or
  * 0 on failure / when `cap` is too small (call with cap = 0 to size the buffer: returns the needed size negated). */
 long long dryv_h264_encode_idr(const dryv_frame_params* fp, const dryv_mb_desc* mbs, const int16_t* coeffs, int slice_qp,

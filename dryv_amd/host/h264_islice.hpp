@@ -210,6 +210,7 @@ inline Pps parse_pps(const std::vector<uint8_t>& rbsp) {  // 7.3.2.2 (atom/avcc/
 
 struct SliceHeader {
   int first_mb = 0, slice_type = 0, frame_num = 0, idr_pic_id = 0, slice_qp = 26;
+  int disable_deblocking_filter_idc = 0, alpha_c0_offset_div2 = 0, beta_offset_div2 = 0;  // slice/header.rs:609-640
   size_t data_bit_pos = 0;  // where slice_data() starts (byte aligned for CABAC)
 };
 inline SliceHeader parse_slice_header(BitReader& r, const Sps& s, const Pps& p, int nal_unit_type, int nal_ref_idc) {
@@ -245,10 +246,14 @@ inline SliceHeader parse_slice_header(BitReader& r, const Sps& s, const Pps& p, 
   }
   h.slice_qp = p.pic_init_qp + r.se();
   if (p.deblocking_control) {
-    if (r.ue() != 1) {
-      r.se();
-      r.se();
+    h.disable_deblocking_filter_idc = (int)r.ue();
+    if (h.disable_deblocking_filter_idc != 1) {
+      h.alpha_c0_offset_div2 = r.se();
+      h.beta_offset_div2 = r.se();
     }
+    if (h.disable_deblocking_filter_idc > 2 || h.alpha_c0_offset_div2 < -6 || h.alpha_c0_offset_div2 > 6 || h.beta_offset_div2 < -6 ||
+        h.beta_offset_div2 > 6)
+      fail("slice header: deblocking syntax elements out of range");
   }
   if (h.first_mb != 0) fail("unsupported: more than one slice per picture");
   return h;
@@ -443,6 +448,9 @@ struct ParsedFrame {
   // the SPS's frame cropping rectangle in luma samples (left, right, top, bottom): sps.rs:252-267. The reference parses
   // and ignores it; here it is handed to the caller, who may pass it on to the output stage (dryv_output_desc)
   int crop[4] = {0, 0, 0, 0};
+  // the slice header's deblocking syntax elements (parsed and unused by the reference: header.rs:609-640, README.md:15);
+  // what dryv_recon_deblock_device takes
+  dryv_deblock_params deblock = {0, 0, 0, 0};
 };
 
 // Shared walk over the macroblock layer; CODER is CabacDecoder (fills mbs/coeffs) or CabacEncoder (reads them).
@@ -833,6 +841,9 @@ inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, 
   }
   F.slice_qp = h.slice_qp;
   for (int k = 0; k < 4; k++) F.crop[k] = 2 * s.crop[k];  // CropUnitX = CropUnitY = 2 for 4:2:0 frame pictures (7.4.2.1.1)
+  F.deblock.disable_deblocking_filter_idc = (uint8_t)h.disable_deblocking_filter_idc;
+  F.deblock.slice_alpha_c0_offset_div2 = (int8_t)h.alpha_c0_offset_div2;
+  F.deblock.slice_beta_offset_div2 = (int8_t)h.beta_offset_div2;
   CabacDecoder cd;
   cd.start(&r, h.slice_qp);
   MbLayer<false, CabacDecoder> L(cd, W, H, p.transform8x8, h.slice_qp);

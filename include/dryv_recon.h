@@ -172,6 +172,11 @@ typedef struct {
 int dryv_recon_deblock_device(dryv_recon_ctx *ctx, const dryv_frame_params *fp, const dryv_deblock_params *dp,
                               uint32_t n_frames, const void *d_mbs, void *d_yuv);
 
+/* dryv_recon_wait with the stages behind reconstruction: blocks until the batch submitted with dryv_recon_submit is done,
+ * then deblocks it (dp; NULL: not), crops / packs it (od; NULL: the full planar pictures) and copies the result into out. */
+int dryv_recon_wait_filtered(dryv_recon_ctx *ctx, const dryv_deblock_params *dp, const dryv_output_desc *od, uint8_t *out,
+                             size_t out_bytes);
+
 /* Device time of the most recent reconstruction kernel launch, from HIP events recorded on the
  * context's own stream immediately around the launch. Valid after wait/sync. */
 int dryv_recon_last_kernel_ms(dryv_recon_ctx *ctx, float *ms);

@@ -132,3 +132,48 @@ def test_deblock_on_gpu(recon_ctx, geo):
         assert np.array_equal(got, want), int(np.flatnonzero(got != want)[0])
     with pytest.raises(Exception):
         recon_ctx.deblock_device(fp, abi.make_deblock_params(0, 9, 0), frames, d_m.data_ptr(), d_y.data_ptr())
+
+
+@pytest.mark.gpu
+def test_host_path_with_deblocking_and_packing(recon_ctx):
+    """dryv_recon_submit + dryv_recon_wait_filtered: reconstruction, deblocking and the output stage chained on the device,
+    only the wanted bytes copied back: equal to oracle reconstruction -> oracle deblocking -> cropping in numpy."""
+    from test_recon_gpu import _expected_packed
+    W, H, frames = 12, 9, 2
+    fp = abi.make_frame_params(W, H)
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.6, i8x8=0.0, qp=(20, 48)), 808, 0, frames)
+    st, yuv = oracle.reconstruct(fp, frames, mbs, co)
+    dp = abi.make_deblock_params(0, 2, 1)
+    st, filt = oracle.deblock(fp, dp, frames, mbs, yuv)
+    for od, crop in ((None, (0, 0, 0, 0)), (abi.make_output_desc(abi.OUT_NV12, (2, 0, 0, 8)), (2, 0, 0, 8))):
+        recon_ctx.submit(fp, frames, mbs, co)
+        got = recon_ctx.wait_filtered(dp, od)
+        want = filt if od is None else _expected_packed(filt, W, H, frames, abi.OUT_NV12, crop)
+        assert np.array_equal(got, want)
+    recon_ctx.submit(fp, frames, mbs, co)
+    assert np.array_equal(recon_ctx.wait_filtered(None, None), yuv)     # no stage: the plain pictures
+
+
+@pytest.mark.gpu
+def test_real_picture_reconstructed_and_deblocked(tmp_path):
+    """The first picture of the real .mp4 with its slice header's own deblocking parameters, through `frame_harness
+    decode-deblocked` (host parse -> GPU reconstruction -> GPU deblocking): equal to the oracles' result, different from the
+    undeblocked picture, and -- a natural image coded at qp 31 -- less blocky across macroblock edges than it."""
+    import os
+    import subprocess
+    from dryv_amd import _build, h264
+    fixture = os.path.join(os.path.dirname(__file__), "golden", "realshort.mp4")
+    exe = _build.build_harness()
+    out = tmp_path / "deblocked.yuv"
+    r = subprocess.run([exe, "decode-deblocked", fixture, str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "disable_idc 0" in r.stdout, (r.stdout, r.stderr)
+    fp, mbs, co, info = h264.parse_first_islice(open(fixture, "rb").read())
+    st, yuv = oracle.reconstruct(fp, 1, mbs, co)
+    st, want = oracle.deblock(fp, info["deblock"], 1, mbs, yuv)
+    got = np.fromfile(str(out), dtype=np.uint8)
+    assert np.array_equal(got, want) and not np.array_equal(got, yuv)
+    Y0 = yuv[:320 * 240].reshape(240, 320).astype(np.int64)
+    Y1 = got[:320 * 240].reshape(240, 320).astype(np.int64)
+    step0 = np.abs(Y0[:, 16::16] - Y0[:, 15:-1:16]).mean() + np.abs(Y0[16::16] - Y0[15:-1:16]).mean()
+    step1 = np.abs(Y1[:, 16::16] - Y1[:, 15:-1:16]).mean() + np.abs(Y1[16::16] - Y1[15:-1:16]).mean()
+    assert step1 < step0
