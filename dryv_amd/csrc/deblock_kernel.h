@@ -9,8 +9,9 @@
 // (x+1, r-1)'s left edge rewrites the three right-most columns of (x, r-1), also (x+1, r-1) -- hence:
 //   * a band = 4 macroblock rows of one picture in lockstep, row g at macroblock x = s - 2g, 16 lanes per macroblock:
 //     one lane per pixel row for vertical edges, per pixel column for horizontal edges (chroma: 8 + 8 lanes for Cb + Cr);
-//   * one wave per band (the filter is a fraction of reconstruction's work per macroblock: no teams), bands off one queue
-//     in band-major order, any number resident;
+//   * one wave per band and plane kind: luma and chroma never meet in this filter, so half the waves of a launch filter
+//     luma and the other half Cb + Cr, each kind with its own band queue (band-major order, any number resident), progress
+//     words and side buffer -- a step's latency is then the longer of the two instead of their sum;
 //   * macroblocks live in a two-macroblock-wide LDS tile per row with four rows of the macroblock above on top. A
 //     macroblock is final towards the left once its right neighbour's left edge has been filtered, and its bottom four
 //     rows only once the macroblock below has filtered its top edge: rows 0..11 are stored one step late by the row
@@ -34,9 +35,10 @@ struct Args {
   const dryv_mb_desc* mbs;
   uint8_t* yuv;
   unsigned* status;        // bit 2 (value 4): a band gave up waiting (words 1..3: where)
-  unsigned* taskCounter;
-  unsigned* prog;          // [frame][band]: macroblocks of the band's last row whose bottom rows are in the side buffer
-  uint8_t* side;           // [frame][band][W][96]: 4 luma rows x 16, then Cb rows 6, 7 and Cr rows 6, 7 x 8
+  // per plane kind (0 luma, 1 chroma):
+  unsigned* taskCounter[2];
+  unsigned* prog[2];       // [frame][band]: macroblocks of the band's last row whose bottom rows are in the side buffer
+  uint8_t* side[2];        // [frame][band][W][64]: 4 luma rows x 16   /   [frame][band][W][32]: Cb rows 6, 7 and Cr rows 6, 7 x 8
 };
 
 // per-workgroup tables
@@ -50,7 +52,7 @@ constexpr int S_RING = S_CTILE + 4 * 2 * 10 * CSTR;       // u8 [4][4 entries][4
 constexpr int S_RINGC = S_RING + 4 * 256;                 // u8 [4][4 entries][2][2 rows][8]
 constexpr int S_BYTES = (S_RINGC + 4 * 128 + 63) & ~63;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-constexpr int SIDE_ENTRY = 96;
+constexpr int SIDE_Y = 64, SIDE_C = 32;
 
 WV void build_tables(const DParams& P, int ldsBase, int tid, int nthreads) {
   for (int k = tid; k < 52; k += nthreads) {
@@ -135,7 +137,8 @@ WV void unpack4(unsigned w, int v[4]) {
 }
 WV unsigned pack4(const int v[4]) { return (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24); }
 
-// One wave: claims bands until none are left. ldsBase: the workgroup's tables; ts: this wave's scratch.
+// One wave: claims bands of its plane kind until none are left. ldsBase: the workgroup's tables; ts: this wave's scratch.
+template <bool LUMA>
 WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
   const int W = P.W, H = P.H, nF = P.n_frames;
@@ -147,7 +150,7 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
 
   for (;;) {
     // (every lane takes part in the claim: see band_kernel.h, "exec-mask hazard")
-    const unsigned tsk = wv::atomic_add_task(A.taskCounter, lane0 == 0 ? 1u : 0u);
+    const unsigned tsk = wv::atomic_add_task(A.taskCounter[LUMA ? 0 : 1], lane0 == 0 ? 1u : 0u);
     const unsigned task = (unsigned)wv::rfl((int)tsk);
     if (task >= totalTasks) break;
     const int b = (int)(task / (unsigned)nF), f = (int)(task - (unsigned)b * (unsigned)nF);
@@ -156,9 +159,10 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
     const bool hasAbove = b > 0, hasBelow = r0 + nR < H;
     uint8_t* const plane = A.yuv + (size_t)f * frameBytes;
     const dryv_mb_desc* const mbsF = A.mbs + (size_t)f * W * H;
-    unsigned* const myProg = A.prog + (size_t)f * nBands + b;
+    constexpr int SIDE_ENTRY = LUMA ? SIDE_Y : SIDE_C;
+    unsigned* const myProg = A.prog[LUMA ? 0 : 1] + (size_t)f * nBands + b;
     const unsigned* const upProg = myProg - 1;
-    uint8_t* const mySide = A.side + ((size_t)f * nBands + b) * (size_t)W * SIDE_ENTRY;
+    uint8_t* const mySide = A.side[LUMA ? 0 : 1] + ((size_t)f * nBands + b) * (size_t)W * SIDE_ENTRY;
     const uint8_t* const upSide = mySide - (size_t)W * SIDE_ENTRY;
 
     const int lane = lane0;
@@ -177,15 +181,18 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
     unsigned dCur = 0, dTop = 0;
     auto prefetch = [&](int x) {
       if (rowOk && x >= 0 && x < W) {
-        rowY = wv::ld_u128_a2(plane + (size_t)(16 * r + i) * pitchY + 16 * x);
-        rowC = *(const u32x2*)(plane + (cpl ? offCr : offCb) + (size_t)(8 * r + crow) * pitchC + 8 * x);
+        if (LUMA) rowY = wv::ld_u128_a2(plane + (size_t)(16 * r + i) * pitchY + 16 * x);
+        else rowC = *(const u32x2*)(plane + (cpl ? offCr : offCb) + (size_t)(8 * r + crow) * pitchC + 8 * x);
         dCur = *(const unsigned*)(mbsF + (size_t)r * W + x);
         if (mbB) dTop = *(const unsigned*)(mbsF + (size_t)(r - 1) * W + x);
       }
     };
     prefetch(-2 * g);
     int qpLeft = 0;
-    unsigned upKnown = 0;
+    unsigned upKnown = 0, flagV = 0;
+    bool flagPend = false, haveN = false;
+    u32x4 topYn = {0, 0, 0, 0};  // the band above's rows for the NEXT step, requested a step early when it is far enough ahead
+    u32x2 topCn = {0, 0};
     bool linePend = false;
     unsigned pubCount = 0;
 
@@ -200,15 +207,26 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       const u32x4 curY = rowY;
       const u32x2 curC = rowC;
 
-      // ---- publish what the previous step handed to the band below; fetch what the band above hands to row 0 -------
-      if (linePend) {
-        wv::wait_vm(0);
-        if (lane == 0) wv::st_sc1(myProg, pubCount);
-        linePend = false;
-      }
+      // ---- fetch what the band above hands to row 0: its progress word is read one step ahead, and so are the rows themselves
+      // whenever it has got that far (the request then has a whole step to come back)
       u32x4 topY = {0, 0, 0, 0};
       u32x2 topC = {0, 0};
+      auto fetch_side = [&](int mb, u32x4& y, u32x2& c) {
+        const unsigned* e = (const unsigned*)(upSide + (size_t)mb * SIDE_ENTRY);
+        if (LUMA && lane < 4) {
+          y.x = wv::ld_sc1(e + 4 * lane);
+          y.y = wv::ld_sc1(e + 4 * lane + 1);
+          y.z = wv::ld_sc1(e + 4 * lane + 2);
+          y.w = wv::ld_sc1(e + 4 * lane + 3);
+        } else if (!LUMA && lane >= 4 && lane < 8) {
+          c.x = wv::ld_sc1(e + 2 * (lane - 4));
+          c.y = wv::ld_sc1(e + 2 * (lane - 4) + 1);
+        }
+      };
+      bool haveNext = false;
       if (hasAbove && s < W) {  // row 0 is at macroblock s: the band above must have handed over macroblock s
+        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
+        flagPend = false;
         unsigned spins = 0;
         while (upKnown < (unsigned)(s + 1)) {
           const unsigned v = wv::ld_sc1(upProg);
@@ -227,32 +245,38 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
           }
         }
         wv::compiler_fence();
-        const unsigned* e = (const unsigned*)(upSide + (size_t)s * SIDE_ENTRY);
-        if (lane < 4) {
-          topY.x = wv::ld_sc1(e + 4 * lane);
-          topY.y = wv::ld_sc1(e + 4 * lane + 1);
-          topY.z = wv::ld_sc1(e + 4 * lane + 2);
-          topY.w = wv::ld_sc1(e + 4 * lane + 3);
-        } else if (lane < 8) {
-          topC.x = wv::ld_sc1(e + 16 + 2 * (lane - 4));
-          topC.y = wv::ld_sc1(e + 16 + 2 * (lane - 4) + 1);
+        if (haveN) {
+          topY = topYn;
+          topC = topCn;
+        } else {
+          fetch_side(s, topY, topC);
+        }
+        haveNext = s + 1 < W && upKnown >= (unsigned)(s + 2);
+        if (haveNext) fetch_side(s + 1, topYn, topCn);
+        if (upKnown < (unsigned)W) {
+          flagV = wv::ld_sc1(upProg);
+          flagPend = true;
         }
       }
+      haveN = haveNext;
       // the next step's macroblock (its registers are free: curY / curC hold this step's)
       prefetch(x + 1);
 
       // ---- tile: this macroblock's rows, the four (two) rows above it -------------------------------------------------
       if (proc) {
-        const int d = tile + LSTR * (4 + i) + 16 * slot;
-        wv::lds_st32(d, curY.x);
-        wv::lds_st32(d + 4, curY.y);
-        wv::lds_st32(d + 8, curY.z);
-        wv::lds_st32(d + 12, curY.w);
-        const int dc = ctile + CSTR * (2 + crow) + 8 * slot;
-        wv::lds_st32(dc, curC.x);
-        wv::lds_st32(dc + 4, curC.y);
+        if (LUMA) {
+          const int d = tile + LSTR * (4 + i) + 16 * slot;
+          wv::lds_st32(d, curY.x);
+          wv::lds_st32(d + 4, curY.y);
+          wv::lds_st32(d + 8, curY.z);
+          wv::lds_st32(d + 12, curY.w);
+        } else {
+          const int dc = ctile + CSTR * (2 + crow) + 8 * slot;
+          wv::lds_st32(dc, curC.x);
+          wv::lds_st32(dc + 4, curC.y);
+        }
         if (mbB) {
-          if (i < 4) {
+          if (LUMA && i < 4) {
             u32x4 t = topY;
             if (g > 0) {
               const int rs = ts + S_RING + 256 * (g - 1) + 64 * (x & 3) + 16 * i;
@@ -263,7 +287,7 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
             wv::lds_st32(dt + 4, t.y);
             wv::lds_st32(dt + 8, t.z);
             wv::lds_st32(dt + 12, t.w);
-          } else if (i < 8) {
+          } else if (!LUMA && i >= 4 && i < 8) {
             const int pl = (i - 4) >> 1, rw = (i - 4) & 1;
             u32x2 t = topC;
             if (g > 0) {
@@ -279,7 +303,7 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       wv::wave_sync();
 
       // ---- vertical edges: lane = pixel row ----------------------------------------------------------------------------
-      if (proc) {
+      if (proc && LUMA) {
         const int rowB = tile + LSTR * (4 + i);
         int p[4], q[4][4];
         unpack4(wv::lds_u32(rowB + 16 * other + 12), p);
@@ -294,6 +318,8 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
         if (mbA) wv::lds_st32(rowB + 16 * other + 12, pack4(p));
 #pragma unroll
         for (int e = 0; e < 4; e++) wv::lds_st32(rowB + 16 * slot + 4 * e, pack4(q[e]));
+      }
+      if (proc && !LUMA) {
         // chroma: lane = (plane, row); edges at x = 0 (macroblock edge) and x = 4
         const int crowB = ctile + CSTR * (2 + crow);
         const int qc = (int)wv::lds_u8(qpcT + qp), qcL = (int)wv::lds_u8(qpcT + qpLeft);
@@ -311,7 +337,7 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       wv::wave_sync();
 
       // ---- horizontal edges: lane = pixel column ------------------------------------------------------------------------
-      if (proc) {
+      if (proc && LUMA) {
         const int colB = tile + 16 * slot + i;
         int v[20];
 #pragma unroll
@@ -325,6 +351,8 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
 #pragma unroll
         for (int j = 1; j < 18; j++)
           if (j >= 4 || mbB) wv::lds_st8(colB + LSTR * j, (unsigned)v[j]);
+      }
+      if (proc && !LUMA) {
         // chroma: lane = (plane, column); rows -2..7
         const int ccolB = ctile + 8 * slot + crow;
         const int qc = (int)wv::lds_u8(qpcT + qp), qcT = (int)wv::lds_u8(qpcT + qpT);
@@ -344,42 +372,50 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       // ---- bottom rows for the row below: this macroblock's as they are now, the left one's columns 12..15 as patched --
       if (proc && g < gl) {
         const int rs = ts + S_RING + 256 * g + 64 * (x & 3) + 4 * i;  // (row 12 + (i >> 2), dword i & 3)
-        wv::lds_st32(rs, wv::lds_u32(tile + LSTR * (16 + (i >> 2)) + 16 * slot + 4 * (i & 3)));
-        if (i < 8) {  // (plane i >> 2, row 6 + ((i >> 1) & 1), dword i & 1)
+        if (LUMA) wv::lds_st32(rs, wv::lds_u32(tile + LSTR * (16 + (i >> 2)) + 16 * slot + 4 * (i & 3)));
+        if (!LUMA && i < 8) {  // (plane i >> 2, row 6 + ((i >> 1) & 1), dword i & 1)
           const int src = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * (i >> 2) + CSTR * (8 + ((i >> 1) & 1)) + 8 * slot + 4 * (i & 1);
           wv::lds_st32(ts + S_RINGC + 128 * g + 32 * (x & 3) + 4 * i, wv::lds_u32(src));
         }
       }
       if (fin && x < W && g < gl) {
-        if (i < 4) {
+        if (LUMA && i < 4) {
           wv::lds_st32(ts + S_RING + 256 * g + 64 * ((x - 1) & 3) + 16 * i + 12, wv::lds_u32(tile + LSTR * (16 + i) + 16 * other + 12));
-        } else if (i < 8) {
+        } else if (!LUMA && i >= 4 && i < 8) {
           const int pl = (i - 4) >> 1, rw = (i - 4) & 1;
           const int src = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * pl + CSTR * (8 + rw) + 8 * other + 4;
           wv::lds_st32(ts + S_RINGC + 128 * g + 32 * ((x - 1) & 3) + 16 * pl + 8 * rw + 4, wv::lds_u32(src));
         }
       }
+      // ---- publish what the PREVIOUS step handed to the band below: its write-through stores have had this whole step to drain
+      if (linePend) {
+        wv::wait_vm(0);
+        if (lane == 0) wv::st_sc1(myProg, pubCount);
+        linePend = false;
+      }
       // ---- stores: macroblock x - 1 is final except for its bottom rows; the macroblock above is final ----------------
       const bool lastRow = r == H - 1;
       if (fin) {
         const int xl = x - 1;
-        const int src = tile + LSTR * (4 + i) + 16 * other;
-        const u32x4 vy = u32x4{wv::lds_u32(src), wv::lds_u32(src + 4), wv::lds_u32(src + 8), wv::lds_u32(src + 12)};
-        if (i < 12 || lastRow) wv::st_g128(plane + (size_t)(16 * r + i) * pitchY + 16 * xl, vy);
-        const int csrc = ctile + CSTR * (2 + crow) + 8 * other;
-        const u32x2 vc = u32x2{wv::lds_u32(csrc), wv::lds_u32(csrc + 4)};
-        if (crow < 6 || lastRow) wv::st_g64(plane + (cpl ? offCr : offCb) + (size_t)(8 * r + crow) * pitchC + 8 * xl, vc);
-        if (hasBelow && g == gl) {  // the band's last row: its bottom rows go to the band below through the side buffer
-          unsigned* e = (unsigned*)(mySide + (size_t)xl * SIDE_ENTRY);
-          if (i >= 12) {
+        unsigned* e = (unsigned*)(mySide + (size_t)xl * SIDE_ENTRY);
+        const bool toBelow = hasBelow && g == gl;  // the band's last row: its bottom rows go to the band below through the side buffer
+        if (LUMA) {
+          const int src = tile + LSTR * (4 + i) + 16 * other;
+          const u32x4 vy = u32x4{wv::lds_u32(src), wv::lds_u32(src + 4), wv::lds_u32(src + 8), wv::lds_u32(src + 12)};
+          if (i < 12 || lastRow) wv::st_g128(plane + (size_t)(16 * r + i) * pitchY + 16 * xl, vy);
+          if (toBelow && i >= 12) {
             wv::st_sc1(e + 4 * (i - 12), vy.x);
             wv::st_sc1(e + 4 * (i - 12) + 1, vy.y);
             wv::st_sc1(e + 4 * (i - 12) + 2, vy.z);
             wv::st_sc1(e + 4 * (i - 12) + 3, vy.w);
           }
-          if (crow >= 6) {
-            wv::st_sc1(e + 16 + 4 * cpl + 2 * (crow - 6), vc.x);
-            wv::st_sc1(e + 16 + 4 * cpl + 2 * (crow - 6) + 1, vc.y);
+        } else {
+          const int csrc = ctile + CSTR * (2 + crow) + 8 * other;
+          const u32x2 vc = u32x2{wv::lds_u32(csrc), wv::lds_u32(csrc + 4)};
+          if (crow < 6 || lastRow) wv::st_g64(plane + (cpl ? offCr : offCb) + (size_t)(8 * r + crow) * pitchC + 8 * xl, vc);
+          if (toBelow && crow >= 6) {
+            wv::st_sc1(e + 4 * cpl + 2 * (crow - 6), vc.x);
+            wv::st_sc1(e + 4 * cpl + 2 * (crow - 6) + 1, vc.y);
           }
         }
       }
@@ -388,11 +424,11 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
         pubCount = (unsigned)(s - 2 * gl);  // macroblocks 0 .. x - 1 of the last row are in the side buffer
       }
       if (proc && mbB) {  // the macroblock above: its bottom four (two) rows are final now
-        if (i < 4) {
+        if (LUMA && i < 4) {
           const int src = tile + LSTR * i + 16 * slot;
           wv::st_g128(plane + (size_t)(16 * (r - 1) + 12 + i) * pitchY + 16 * x,
                       u32x4{wv::lds_u32(src), wv::lds_u32(src + 4), wv::lds_u32(src + 8), wv::lds_u32(src + 12)});
-        } else if (i < 8) {
+        } else if (!LUMA && i >= 4 && i < 8) {
           const int pl = (i - 4) >> 1, rw = (i - 4) & 1;
           const int src = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * pl + CSTR * rw + 8 * slot;
           wv::st_g64(plane + (pl ? offCr : offCb) + (size_t)(8 * (r - 1) + 6 + rw) * pitchC + 8 * x, u32x2{wv::lds_u32(src), wv::lds_u32(src + 4)});

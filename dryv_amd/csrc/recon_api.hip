@@ -375,7 +375,7 @@ int dryv_recon_deblock_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, 
   hipError_t e = hipMemsetAsync(ctx->d_dbwork, 0, dryv::deblock::reset_bytes(P), ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(deblock workspace)");
-  const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
+  const long long tasks = 2ll * P.n_frames * ((P.H + 3) / 4);  // a luma and a chroma task per band
   const int wpb = dryv::deblock_waves_per_block();
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::deblock_blocks_per_cu();
   grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));

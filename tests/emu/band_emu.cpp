@@ -191,7 +191,10 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
 
 static dryv::deblock::DParams g_DP;
 static dryv::deblock::Args g_DA;
-static void deblock_body() { dryv::deblock::deblock_wave(g_DP, g_DA, 0, dryv::deblock::T_END); }
+static void deblock_body() {  // even waves: luma, odd waves: chroma
+  if (wave_index() & 1) dryv::deblock::deblock_wave<false>(g_DP, g_DA, 0, dryv::deblock::T_END);
+  else dryv::deblock::deblock_wave<true>(g_DP, g_DA, 0, dryv::deblock::T_END);
+}
 
 // n_waves independent band waves (each with its own LDS), scheduled round-robin from `first`, `order` = +1 / -1.
 extern "C" int dryv_emu_deblock(const dryv_frame_params* fp, const dryv_deblock_params* dp, uint32_t n_frames, const dryv_mb_desc* mbs,
@@ -202,11 +205,14 @@ extern "C" int dryv_emu_deblock(const dryv_frame_params* fp, const dryv_deblock_
   if (status_out) *status_out = 0;
   if (skip) return DRYV_OK;
   if (n_waves < 1) n_waves = 1;
+  n_waves *= 2;  // a luma and a chroma wave each
   std::vector<uint8_t> ws(dryv::deblock::workspace_bytes(g_DP), 0xC3);
   memset(ws.data(), 0, dryv::deblock::reset_bytes(g_DP));
   unsigned status[4] = {0, 0, 0, 0};
-  g_DA = dryv::deblock::Args{mbs, yuv, status, (unsigned*)ws.data(), (unsigned*)(ws.data() + 256),
-                             ws.data() + dryv::deblock::reset_bytes(g_DP)};
+  g_DA.mbs = mbs;
+  g_DA.yuv = yuv;
+  g_DA.status = status;
+  dryv::deblock::place_workspace(g_DP, ws.data(), &g_DA);
   wv::g_body = deblock_body;
   const int ldsBytes = dryv::deblock::T_END + dryv::deblock::S_BYTES;
   std::vector<std::unique_ptr<wv::Wave>> waves;
@@ -220,15 +226,15 @@ extern "C" int dryv_emu_deblock(const dryv_frame_params* fp, const dryv_deblock_
     wv::g_emu_cur = &waves.back()->st;
     dryv::deblock::build_tables(g_DP, 0, 0, 1);
   }
-  const size_t nProg = (size_t)n_frames * ((g_DP.H + 3) / 4);
+  const size_t nProg = 2 * (size_t)n_frames * ((g_DP.H + 3) / 4);
   int live = n_waves;
   unsigned long long idle_rounds = 0;
   for (int k = 0; live > 0; k++) {
     wv::Wave* w = waves[(((first + order * k) % n_waves) + n_waves) % n_waves].get();
     if (w->finished) continue;
     auto progress = [&]() {
-      unsigned long long t = *g_DA.taskCounter;
-      for (size_t q = 0; q < nProg; q++) t += g_DA.prog[q];
+      unsigned long long t = *g_DA.taskCounter[0] + *g_DA.taskCounter[1];
+      for (size_t q = 0; q < nProg; q++) t += g_DA.prog[0][q];
       return t;
     };
     const unsigned long long before = progress();
