@@ -387,6 +387,21 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
           wv::lds_st32(ts + S_RINGC + 128 * g + 32 * ((x - 1) & 3) + 16 * pl + 8 * rw + 4, wv::lds_u32(src));
         }
       }
+      // The registers requested for the next step are "used" here, in front of this step's stores: the compiler then waits for
+      // those loads now (they were issued a step's worth of cycles ago) instead of at the top of the next step, where its
+      // vmcnt(0) would also wait for the stores below to be acknowledged (band_kernel.h has the same construction).
+      if (LUMA) {
+        rowY.x = (unsigned)wv::opaque((int)rowY.x); rowY.y = (unsigned)wv::opaque((int)rowY.y);
+        rowY.z = (unsigned)wv::opaque((int)rowY.z); rowY.w = (unsigned)wv::opaque((int)rowY.w);
+        topYn.x = (unsigned)wv::opaque((int)topYn.x); topYn.y = (unsigned)wv::opaque((int)topYn.y);
+        topYn.z = (unsigned)wv::opaque((int)topYn.z); topYn.w = (unsigned)wv::opaque((int)topYn.w);
+      } else {
+        rowC.x = (unsigned)wv::opaque((int)rowC.x); rowC.y = (unsigned)wv::opaque((int)rowC.y);
+        topCn.x = (unsigned)wv::opaque((int)topCn.x); topCn.y = (unsigned)wv::opaque((int)topCn.y);
+      }
+      dCur = (unsigned)wv::opaque((int)dCur);
+      dTop = (unsigned)wv::opaque((int)dTop);
+      flagV = (unsigned)wv::opaque((int)flagV);
       // ---- publish what the PREVIOUS step handed to the band below: its write-through stores have had this whole step to drain
       if (linePend) {
         wv::wait_vm(0);
