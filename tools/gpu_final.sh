@@ -17,5 +17,6 @@ timeout -k 10 300 python tools/host_path_rate.py --frames 100 --reps 4 --out $O/
 timeout -k 10 200 python tools/pack_rate.py 300 --out $O/pack_rate.json > $O/pack_rate.log 2>&1 || { echo "pack rate failed"; tail -5 $O/pack_rate.log; exit 1; }
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate tools/micro/valu_rate.hip && timeout -k 5 120 /tmp/valu_rate > $O/valu_rate.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mem_pattern tools/micro/mem_pattern.hip && timeout -k 5 120 /tmp/mem_pattern > $O/mem_pattern.txt 2>&1
+timeout -k 10 300 python tools/deblock_rate.py 300 --out $O/deblock_rate.json > $O/deblock_rate.log 2>&1 || { echo "deblock rate failed"; tail -5 $O/deblock_rate.log; exit 1; }
 timeout -k 10 600 python tools/stream_rate.py 300 --out $O/stream_rate.json > $O/stream_rate.log 2>&1 || { echo "stream rate failed"; tail -5 $O/stream_rate.log; exit 1; }
 echo "all ok"
