@@ -8,10 +8,14 @@
 namespace dryv {
 
 #ifndef DRYV_DEBLOCK_WAVES
-#define DRYV_DEBLOCK_WAVES 4   // independent band waves per workgroup
+#define DRYV_DEBLOCK_WAVES 3   // independent band waves per workgroup (tools/db_variants.sh)
+#endif
+#ifndef DRYV_DEBLOCK_CHROMA_EVERY
+#define DRYV_DEBLOCK_CHROMA_EVERY 3
 #endif
 #ifndef DRYV_DEBLOCK_WGS_PER_CU
-#define DRYV_DEBLOCK_WGS_PER_CU 2   // (measured: 512 workgroups 3.0 ms, 1024 3.4, 256 3.7 on 300 x 1080p)
+#define DRYV_DEBLOCK_WGS_PER_CU 2   // 2 x (2 luma + 1 chroma waves) per CU measured best on 300 x 1080p: 2.61 ms (4 + 2 in one
+                                    // workgroup 2.65, 2 + 2 in two 2.8, 9 or 12 waves per CU 2.9 - 3.0, 3 or 4 per CU 3.3 - 3.7)
 #endif
 
 __global__ void __launch_bounds__(64 * DRYV_DEBLOCK_WAVES) deblock_kernel(const deblock::DParams P, deblock::Args A) {
@@ -20,8 +24,9 @@ __global__ void __launch_bounds__(64 * DRYV_DEBLOCK_WAVES) deblock_kernel(const 
   deblock::build_tables(P, ldsBase, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();  // the only workgroup-level synchronisation: the waves are independent from here on
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // even waves filter luma, odd waves Cb + Cr (two independent band queues)
-  if (wave & 1) deblock::deblock_wave<false>(P, A, ldsBase, ldsBase + deblock::T_END + wave * deblock::S_BYTES);
+  // one wave in DRYV_DEBLOCK_CHROMA_EVERY filters Cb + Cr, the others luma (two independent band queues; a luma band takes
+  // about twice as long as a chroma band)
+  if (wave % DRYV_DEBLOCK_CHROMA_EVERY == DRYV_DEBLOCK_CHROMA_EVERY - 1) deblock::deblock_wave<false>(P, A, ldsBase, ldsBase + deblock::T_END + wave * deblock::S_BYTES);
   else deblock::deblock_wave<true>(P, A, ldsBase, ldsBase + deblock::T_END + wave * deblock::S_BYTES);
 }
 
