@@ -110,7 +110,8 @@ def test_emulated_deblock_kernel_matches_oracle(geo):
 
 # ---- the product path ---------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("geo", [(1, 1, 2, False), (7, 5, 3, True), (20, 15, 2, True), (13, 21, 2, False), (120, 68, 2, False)])
+@pytest.mark.parametrize("geo", [(1, 1, 2, False), (7, 5, 3, True), (20, 15, 2, True), (13, 21, 2, False), (120, 68, 2, False),
+                                 (240, 135, 1, True)])
 def test_deblock_on_gpu(recon_ctx, geo):
     """dryv_recon_deblock_device on reconstructed pictures in device memory, against the oracle; after a reconstruction on
     the same context (submit_device -> sync -> deblock_device -> sync), as a decoder would chain them."""
