@@ -262,19 +262,9 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       // the next step's macroblock (its registers are free: curY / curC hold this step's)
       prefetch(x + 1);
 
-      // ---- tile: this macroblock's rows, the four (two) rows above it -------------------------------------------------
+      // ---- tile: the four (two) rows above this macroblock (its own rows go in after the vertical edges, straight from the
+      // registers they were loaded into)
       if (proc) {
-        if (LUMA) {
-          const int d = tile + LSTR * (4 + i) + 16 * slot;
-          wv::lds_st32(d, curY.x);
-          wv::lds_st32(d + 4, curY.y);
-          wv::lds_st32(d + 8, curY.z);
-          wv::lds_st32(d + 12, curY.w);
-        } else {
-          const int dc = ctile + CSTR * (2 + crow) + 8 * slot;
-          wv::lds_st32(dc, curC.x);
-          wv::lds_st32(dc + 4, curC.y);
-        }
         if (mbB) {
           if (LUMA && i < 4) {
             u32x4 t = topY;
@@ -300,15 +290,16 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
           }
         }
       }
-      wv::wave_sync();
 
       // ---- vertical edges: lane = pixel row ----------------------------------------------------------------------------
       if (proc && LUMA) {
         const int rowB = tile + LSTR * (4 + i);
         int p[4], q[4][4];
         unpack4(wv::lds_u32(rowB + 16 * other + 12), p);
-#pragma unroll
-        for (int e = 0; e < 4; e++) unpack4(wv::lds_u32(rowB + 16 * slot + 4 * e), q[e]);
+        unpack4(curY.x, q[0]);
+        unpack4(curY.y, q[1]);
+        unpack4(curY.z, q[2]);
+        unpack4(curY.w, q[3]);
         const Thr tE = thresholds(ldsBase, qpLeft, qp, P.offA, P.offB), tI = thresholds(ldsBase, qp, qp, P.offA, P.offB);
         filter_line<true, false>(p[0], p[1], p[2], p[3], q[0][0], q[0][1], q[0][2], q[0][3], tE, mbA);
 #pragma unroll
@@ -325,8 +316,8 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
         const int qc = (int)wv::lds_u8(qpcT + qp), qcL = (int)wv::lds_u8(qpcT + qpLeft);
         int cp[4], c0[4], c1[4];
         unpack4(wv::lds_u32(crowB + 8 * other + 4), cp);
-        unpack4(wv::lds_u32(crowB + 8 * slot), c0);
-        unpack4(wv::lds_u32(crowB + 8 * slot + 4), c1);
+        unpack4(curC.x, c0);
+        unpack4(curC.y, c1);
         const Thr cE = thresholds(ldsBase, qcL, qc, P.offA, P.offB), cI = thresholds(ldsBase, qc, qc, P.offA, P.offB);
         filter_line<true, true>(cp[0], cp[1], cp[2], cp[3], c0[0], c0[1], c0[2], c0[3], cE, mbA);
         filter_line<false, true>(c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3], cI, true);
