@@ -360,23 +360,45 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       }
       wv::wave_sync();
 
-      // ---- bottom rows for the row below: this macroblock's as they are now, the left one's columns 12..15 as patched --
-      if (proc && g < gl) {
-        const int rs = ts + S_RING + 256 * g + 64 * (x & 3) + 4 * i;  // (row 12 + (i >> 2), dword i & 3)
-        if (LUMA) wv::lds_st32(rs, wv::lds_u32(tile + LSTR * (16 + (i >> 2)) + 16 * slot + 4 * (i & 3)));
-        if (!LUMA && i < 8) {  // (plane i >> 2, row 6 + ((i >> 1) & 1), dword i & 1)
-          const int src = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * (i >> 2) + CSTR * (8 + ((i >> 1) & 1)) + 8 * slot + 4 * (i & 1);
-          wv::lds_st32(ts + S_RINGC + 128 * g + 32 * (x & 3) + 4 * i, wv::lds_u32(src));
+      // ---- after the filters: everything that leaves the tile is read first (one LDS round trip), then written / stored ----
+      const bool lastRow = r == H - 1;
+      const bool ringA = proc && g < gl, ringB = fin && x < W && g < gl;
+      const bool topOut = proc && mbB;
+      unsigned vA = 0, vB = 0;
+      u32x4 vy = {0, 0, 0, 0}, vt = {0, 0, 0, 0};
+      u32x2 vc = {0, 0}, vtc = {0, 0};
+      if (LUMA) {
+        if (ringA) vA = wv::lds_u32(tile + LSTR * (16 + (i >> 2)) + 16 * slot + 4 * (i & 3));   // (row 12 + (i >> 2), dword i & 3)
+        if (ringB && i < 4) vB = wv::lds_u32(tile + LSTR * (16 + i) + 16 * other + 12);
+        if (fin) {
+          const int src = tile + LSTR * (4 + i) + 16 * other;
+          vy = u32x4{wv::lds_u32(src), wv::lds_u32(src + 4), wv::lds_u32(src + 8), wv::lds_u32(src + 12)};
+        }
+        if (topOut && i < 4) {
+          const int src = tile + LSTR * i + 16 * slot;
+          vt = u32x4{wv::lds_u32(src), wv::lds_u32(src + 4), wv::lds_u32(src + 8), wv::lds_u32(src + 12)};
+        }
+      } else {
+        const int cbase = ts + S_CTILE + 2 * 10 * CSTR * g;
+        if (ringA && i < 8)  // (plane i >> 2, row 6 + ((i >> 1) & 1), dword i & 1)
+          vA = wv::lds_u32(cbase + 10 * CSTR * (i >> 2) + CSTR * (8 + ((i >> 1) & 1)) + 8 * slot + 4 * (i & 1));
+        if (ringB && i >= 4 && i < 8) vB = wv::lds_u32(cbase + 10 * CSTR * ((i - 4) >> 1) + CSTR * (8 + ((i - 4) & 1)) + 8 * other + 4);
+        if (fin) {
+          const int csrc = ctile + CSTR * (2 + crow) + 8 * other;
+          vc = u32x2{wv::lds_u32(csrc), wv::lds_u32(csrc + 4)};
+        }
+        if (topOut && i >= 4 && i < 8) {
+          const int src = cbase + 10 * CSTR * ((i - 4) >> 1) + CSTR * ((i - 4) & 1) + 8 * slot;
+          vtc = u32x2{wv::lds_u32(src), wv::lds_u32(src + 4)};
         }
       }
-      if (fin && x < W && g < gl) {
-        if (LUMA && i < 4) {
-          wv::lds_st32(ts + S_RING + 256 * g + 64 * ((x - 1) & 3) + 16 * i + 12, wv::lds_u32(tile + LSTR * (16 + i) + 16 * other + 12));
-        } else if (!LUMA && i >= 4 && i < 8) {
-          const int pl = (i - 4) >> 1, rw = (i - 4) & 1;
-          const int src = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * pl + CSTR * (8 + rw) + 8 * other + 4;
-          wv::lds_st32(ts + S_RINGC + 128 * g + 32 * ((x - 1) & 3) + 16 * pl + 8 * rw + 4, wv::lds_u32(src));
-        }
+      // bottom rows for the row below: this macroblock's as they are now, the left one's columns 12..15 (4..7) as patched
+      if (LUMA) {
+        if (ringA) wv::lds_st32(ts + S_RING + 256 * g + 64 * (x & 3) + 4 * i, vA);
+        if (ringB && i < 4) wv::lds_st32(ts + S_RING + 256 * g + 64 * ((x - 1) & 3) + 16 * i + 12, vB);
+      } else {
+        if (ringA && i < 8) wv::lds_st32(ts + S_RINGC + 128 * g + 32 * (x & 3) + 4 * i, vA);
+        if (ringB && i >= 4 && i < 8) wv::lds_st32(ts + S_RINGC + 128 * g + 32 * ((x - 1) & 3) + 16 * ((i - 4) >> 1) + 8 * ((i - 4) & 1) + 4, vB);
       }
       // The registers requested for the next step are "used" here, in front of this step's stores: the compiler then waits for
       // those loads now (they were issued a step's worth of cycles ago) instead of at the top of the next step, where its
@@ -400,14 +422,11 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
         linePend = false;
       }
       // ---- stores: macroblock x - 1 is final except for its bottom rows; the macroblock above is final ----------------
-      const bool lastRow = r == H - 1;
       if (fin) {
         const int xl = x - 1;
         unsigned* e = (unsigned*)(mySide + (size_t)xl * SIDE_ENTRY);
         const bool toBelow = hasBelow && g == gl;  // the band's last row: its bottom rows go to the band below through the side buffer
         if (LUMA) {
-          const int src = tile + LSTR * (4 + i) + 16 * other;
-          const u32x4 vy = u32x4{wv::lds_u32(src), wv::lds_u32(src + 4), wv::lds_u32(src + 8), wv::lds_u32(src + 12)};
           if (i < 12 || lastRow) wv::st_g128(plane + (size_t)(16 * r + i) * pitchY + 16 * xl, vy);
           if (toBelow && i >= 12) {
             wv::st_sc1(e + 4 * (i - 12), vy.x);
@@ -416,8 +435,6 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
             wv::st_sc1(e + 4 * (i - 12) + 3, vy.w);
           }
         } else {
-          const int csrc = ctile + CSTR * (2 + crow) + 8 * other;
-          const u32x2 vc = u32x2{wv::lds_u32(csrc), wv::lds_u32(csrc + 4)};
           if (crow < 6 || lastRow) wv::st_g64(plane + (cpl ? offCr : offCb) + (size_t)(8 * r + crow) * pitchC + 8 * xl, vc);
           if (toBelow && crow >= 6) {
             wv::st_sc1(e + 4 * cpl + 2 * (crow - 6), vc.x);
@@ -429,15 +446,12 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
         linePend = true;
         pubCount = (unsigned)(s - 2 * gl);  // macroblocks 0 .. x - 1 of the last row are in the side buffer
       }
-      if (proc && mbB) {  // the macroblock above: its bottom four (two) rows are final now
+      if (topOut) {  // the macroblock above: its bottom four (two) rows are final now
         if (LUMA && i < 4) {
-          const int src = tile + LSTR * i + 16 * slot;
-          wv::st_g128(plane + (size_t)(16 * (r - 1) + 12 + i) * pitchY + 16 * x,
-                      u32x4{wv::lds_u32(src), wv::lds_u32(src + 4), wv::lds_u32(src + 8), wv::lds_u32(src + 12)});
+          wv::st_g128(plane + (size_t)(16 * (r - 1) + 12 + i) * pitchY + 16 * x, vt);
         } else if (!LUMA && i >= 4 && i < 8) {
           const int pl = (i - 4) >> 1, rw = (i - 4) & 1;
-          const int src = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * pl + CSTR * rw + 8 * slot;
-          wv::st_g64(plane + (pl ? offCr : offCb) + (size_t)(8 * (r - 1) + 6 + rw) * pitchC + 8 * x, u32x2{wv::lds_u32(src), wv::lds_u32(src + 4)});
+          wv::st_g64(plane + (pl ? offCr : offCb) + (size_t)(8 * (r - 1) + 6 + rw) * pitchC + 8 * x, vtc);
         }
       }
       if (proc) qpLeft = qp;
