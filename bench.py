@@ -196,13 +196,20 @@ def main():
         achieved = n_mbs * ALG_BYTES_PER_MB / avg_kernel_s / 1e9
         # HBM bytes per launch from the PMC passes of tools/profile_round.sh, quoted only when they were taken on
         # exactly this kernel source (otherwise null: a stale figure is not a measurement of this run)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(args.workload, {})
                 if ent.get("kernel_source_sha") == kernel_source_sha():
                     traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
+                    if ent.get("valu_per_macroblock"):
+                        # the bound that matters for this integer kernel: vector instructions per macroblock
+                        # (SQ_INSTS_VALU) x the measured issue cost of a wave-instruction on one of the chip's 1024 SIMDs
+                        floor_ms = ent["valu_per_macroblock"] * n_mbs / 1024.0 * ent["ns_per_valu_instruction"] * 1e-6
+                        valu = {"per_macroblock": ent["valu_per_macroblock"], "ns_per_instruction_per_simd": ent["ns_per_valu_instruction"],
+                                "floor_ms": floor_ms, "kernel_over_floor": avg_kernel_s * 1e3 / floor_ms,
+                                "source": "SQ_INSTS_VALU (profiles/) and tools/micro/valu_rate.hip"}
             except Exception:
                 traffic = None
         line = {
@@ -224,7 +231,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_source_sha": kernel_source_sha(),
-                         "algorithmic_bytes_per_launch": n_mbs * ALG_BYTES_PER_MB},
+                         "algorithmic_bytes_per_launch": n_mbs * ALG_BYTES_PER_MB, "vector_issue": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fp, mbs, coeffs, n_frames, d_out, frame_bytes,
