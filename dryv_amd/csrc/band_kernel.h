@@ -65,10 +65,10 @@ constexpr int T_END_I8 = 2688;
 // Output staging: a row's pixels are flushed to global memory NSY (luma) / NSC (chroma) macroblocks at a time, as
 // 16 x NSY / 8 x NSC contiguous bytes per pixel row: the wider the segment, the fewer partial lines memory sees.
 #ifndef DRYV_BAND_NSY
-#define DRYV_BAND_NSY 2
+#define DRYV_BAND_NSY 4
 #endif
 #ifndef DRYV_BAND_NSC
-#define DRYV_BAND_NSC 2
+#define DRYV_BAND_NSC 8
 #endif
 constexpr int NSY = DRYV_BAND_NSY, NSC = DRYV_BAND_NSC;
 static_assert((NSY == 2 || NSY == 4 || NSY == 8) && (NSC == 2 || NSC == 4 || NSC == 8), "staging widths");
@@ -1152,13 +1152,15 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         constexpr int LR = 8 * NSC;  // lanes per macroblock row: 2 planes x 8 pixel rows x NSC / 2 segments of 16 bytes
 #pragma unroll
         for (int it = 0; it < NSC / 2; it++) {
-          const int q = lane + 64 * it;
-          const int fg = q / LR, w = q % LR;
-          const int pl = w / (LR / 2), fy = (w / (NSC / 2)) & 7, seg = w % (NSC / 2);
+          // (64 lanes or more per macroblock row: the row and whether it is flushed at all are wave-uniform, decided on
+          // the scalar side before any lane work)
+          const int fg = LR >= 64 ? (64 * it) / LR : (64 / LR) * it + lane / LR;
+          const int w = LR >= 64 ? ((64 * it) % LR) + lane : lane % LR;
           const int fx = s - 2 * fg, xp = fx & ~(NSC - 1);
-          const bool ok = fg < nR && fx >= 0 && fx < W && ((fx & (NSC - 1)) == NSC - 1 || fx == W - 1) && xp + 2 * seg <= fx &&
-                          !(hasBelow && fg == gl && fy == 7);
-          if (NSC >= 8 && !wv::any(ok)) continue;  // (one macroblock row per iteration)
+          const bool rowFlush = fg < nR && fx >= 0 && fx < W && ((fx & (NSC - 1)) == NSC - 1 || fx == W - 1);
+          if (LR >= 64 && !rowFlush) continue;
+          const int pl = w / (LR / 2), fy = (w / (NSC / 2)) & 7, seg = w % (NSC / 2);
+          const bool ok = rowFlush && xp + 2 * seg <= fx && !(hasBelow && fg == gl && fy == 7);
           const u32x4 v = wv::lds_u128(ts + S_STC + 16 * CW * fg + 8 * CW * pl + CW * fy + 16 * seg);
           uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp + 16 * seg));
           if (ok) {
@@ -1510,12 +1512,14 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         constexpr int LR = 16 * NSY;  // lanes per macroblock row: 16 pixel rows x NSY segments of 16 bytes
 #pragma unroll
         for (int it = 0; it < NSY; it++) {
-          const int q = lane + 64 * it;
-          const int fg = q / LR, fy = (q / NSY) & 15, seg = q % NSY;
+          // (64 lanes or more per macroblock row: the row and whether it is flushed at all are wave-uniform)
+          const int fg = LR >= 64 ? (64 * it) / LR : (64 / LR) * it + lane / LR;
+          const int w = LR >= 64 ? ((64 * it) % LR) + lane : lane % LR;
           const int fx = s - 2 * fg, xp = fx & ~(NSY - 1);
-          const bool ok = fg < nR && fx >= 0 && fx < W && ((fx & (NSY - 1)) == NSY - 1 || fx == W - 1) && xp + seg <= fx &&
-                          !(hasBelow && fg == gl && fy == 15);
-          if (NSY >= 4 && !wv::any(ok)) continue;  // (one macroblock row, or half of one, per iteration)
+          const bool rowFlush = fg < nR && fx >= 0 && fx < W && ((fx & (NSY - 1)) == NSY - 1 || fx == W - 1);
+          if (LR >= 64 && !rowFlush) continue;
+          const int fy = (w / NSY) & 15, seg = w % NSY;
+          const bool ok = rowFlush && xp + seg <= fx && !(hasBelow && fg == gl && fy == 15);
           const int src = ts + S_TILE + TILE_BYTES * (NP * fg + (seg >> 1)) + TILE_STRIDE * (fy + 1) + 8 + 16 * (seg & 1);
           const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
           if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + seg)), u32x4{lo.x, lo.y, hi.x, hi.y});

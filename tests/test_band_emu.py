@@ -77,7 +77,7 @@ def test_emulated_teams_run_concurrently(geo):
         check(fp, frames, mbs, co, teams=teams, first=first, order=order)
 
 
-@pytest.mark.parametrize("nsy,nsc", [(2, 2), (8, 4), (4, 2), (2, 8)])
+@pytest.mark.parametrize("nsy,nsc", [(2, 2), (8, 4), (4, 4), (2, 8)])
 def test_emulated_staging_widths(nsy, nsc):
     """The output staging width (macroblocks per flushed row segment) is a build-time choice; every choice must give
     the same pictures, ragged right edges included (widths 11 and 17 are multiples of none of them)."""
