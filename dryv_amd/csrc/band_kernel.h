@@ -54,7 +54,7 @@ constexpr int T_LS4Z = 0;     // u16 [6][16]    LevelScale4x4 in list order
 constexpr int T_QPC = 192;    // u8  [2][52]    QP'c for Cb / Cr as a function of QPY (transform.rs:194-216)
 constexpr int T_THR4 = 304;   // u16 [52]
 constexpr int T_THR8 = 408;   // u16 [52]
-constexpr int T_T4E = 512;    // u32 [12][8][2] Intra4x4 entries [mode][pixel pair][pixel]
+constexpr int T_T4E = 512;    // u32 [8][12][2] Intra4x4 entries [pixel pair][mode][pixel]
 constexpr int T_END = 1280;
 constexpr int T_LS8 = 1280;   // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
 constexpr int T_T8 = 2048;    // u8  [9][64]    Intra8x8 table [mode][y*8+x]: index on the filtered edge | value kind << 5
@@ -78,8 +78,8 @@ constexpr int TILE_BYTES = 704;  // 17 rows x 40 + 8 (row y = -1 of slot 1 reach
 constexpr int NP = NSY / 2;
 constexpr int CW = 8 * NSC;      // chroma staging: bytes per pixel row
 // FRONT -> BACK, double-buffered by the parity of the team's global step count
-constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [blkIdx][y][x]
-constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       Intra4x4 table row per chain step and block half
+constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [4 * by + bx][y][x]
+constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       8 x the Intra4x4 table row per chain step and block half (always a multiple of 8)
 constexpr int S_INFO = 4288;     // u32 [2][8]              kinds of the 4 macroblocks, Intra16x16 modes, task, step
 constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2] (global step count + 1 of the record in / consumed from the
                                  //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks)
@@ -221,7 +221,7 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
       const unsigned pc = (unsigned)(c <= 3 ? (4 - c) * TILE_STRIDE : c - 4);
       v = 2u | (pa << 8) | (pb << 16) | (pc << 24);
     }
-    wv::lds_st32(ldsBase + T_T4E + 4 * k, v);
+    wv::lds_st32(ldsBase + T_T4E + 96 * p + 8 * m + 4 * e, v);
   }
   if (hasI8) {
     for (int k = tid; k < 384; k += nthreads) wv::lds_st16(ldsBase + T_LS8 + 2 * k, P.ls8[k]);
@@ -757,18 +757,20 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       if (gstep >= 2) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - 1);
       if (HAS_I8 && kind == 1) {
         // this lane holds column j = i & 7 of 8x8 blocks i >> 3 (rA[0..3]) and 2 + (i >> 3) (rA[4..7]), rows 2m, 2m+1 per
-        // word: element (row k, column j) goes to 4x4 block 4 * b8 + 2 * (k >> 2) + (j >> 2), position (k & 3, j & 3)
+        // word: element (row k, column j) goes to 4x4 block (bx, by) = (2 * (b8 & 1) + (j >> 2), 2 * (b8 >> 1) + (k >> 2)),
+        // position (k & 3, j & 3)
         const int j = i & 7;
-        const int dst = ts + S_RES + 2048 * buf + 512 * g + 128 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
+        const int dst = ts + S_RES + 2048 * buf + 512 * g + 64 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
 #pragma unroll
         for (int pk = 0; pk < 16; pk++) {
           const int p = pk >> 3, k = pk & 7;
           const unsigned w = rA[4 * p + (k >> 1)];
-          wv::lds_st16(dst + 256 * p + 64 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
+          wv::lds_st16(dst + 256 * p + 128 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
         }
       } else {
-        wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i, u32x4{rA[0], rA[1], rA[2], rA[3]});
-        wv::lds_st128(ts + S_RES + 2048 * buf + 512 * g + 32 * i + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
+        const int dst = ts + S_RES + 2048 * buf + 512 * g + 32 * (4 * zby + zbx);
+        wv::lds_st128(dst, u32x4{rA[0], rA[1], rA[2], rA[3]});
+        wv::lds_st128(dst + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
       }
       if (i == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 4 * g, (unsigned)kind | ((unsigned)i16mode << 8));
       if (lane == 0) {
@@ -830,10 +832,10 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           Mcur = M;
           const int t = rbx + 2 * rby;
           const int hh = rby != stepByLo(t) ? 1 : 0;
-          wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + 12 * hh + t, (unsigned)Mp);
+          wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + 12 * hh + t, (unsigned)(8 * Mp));  // (the table row's offset)
         } else if (is8) {
           Mcur = M;
-          if (((rbx | rby) & 1) == 0) wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + mzb, (unsigned)M);  // BACK: modes of blocks 0..3
+          if (((rbx | rby) & 1) == 0) wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + mzb, (unsigned)(8 * M));  // BACK: modes of blocks 0..3 (x 8: see S_MSEQ)
         }
       }
 
@@ -1318,7 +1320,8 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 #pragma unroll
             for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
           }
-          const u32x4 ra = wv::lds_u128(resBuf + 512 * g + 32 * i), rb = wv::lds_u128(resBuf + 512 * g + 32 * i + 16);
+          const int rsrc = resBuf + 512 * g + 32 * (4 * zby + zbx);
+          const u32x4 ra = wv::lds_u128(rsrc), rb = wv::lds_u128(rsrc + 16);
           const unsigned rA[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
           const int dst = tile + TILE_STRIDE * (4 * zby + 1) + 8 + 16 * slot + 4 * zbx;
 #pragma unroll
@@ -1352,54 +1355,61 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         const bool mine = valid && kind == 0;
         const int px = 2 * (cp & 1), py = cp >> 1;
         const int seqA = ts + S_MSEQ + 96 * buf + 24 * g + 12 * ch;
-        const int tOrg = tile + 8 + 16 * slot;   // row y = -1, x = 0 of the macroblock
-        const int resB = resBuf + 512 * g + 4 * cp;
-        const int entB = ldsBase + T_T4E + 8 * cp;
+        // Everything a round addresses is a per-lane base (computed once per step) plus a constant of the round, which
+        // the LDS instructions carry as their immediate offset: the second block of a two-block round is always
+        // (bx - 2, by + 1) of the first, so its lanes' bases differ from the first block's by a constant (in the rounds
+        // with one block those lanes compute on whatever is there and store nothing).
+        const int orgB = tile + 8 + 16 * slot - 1 + (ch ? 4 * TILE_STRIDE - 8 : 0);  // (block origin - one row - one column) of block (0, 0) / (-2, 1)
+        const int stB = orgB + TILE_STRIDE * (py + 1) + 1 + px;
+        const int resB = resBuf + 512 * g + 4 * cp + (ch ? 64 : 0);   // residuals: [4 * by + bx]
+        const int entB = ldsBase + T_T4E + 96 * cp;
+        const bool chOrB = ch != 0 || mbB, nchOrA = ch == 0 || mbA;
         // the table rows of all ten steps (they do not depend on pixels), then entry and residual one step ahead
         const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
-        u32x2 en = wv::lds_u64(entB + 64 * (int)min(sq0 & 0xffu, 11u));
+        u32x2 en = wv::lds_u64(entB + (int)(sq0 & 0xffu));
         unsigned rr = wv::lds_u32(resB);
-#define I4_BLK(T, h) ((h) && (stepByLo(T) + 1 <= stepByHi(T)) ? zidx((T) - 2 * stepByLo(T) - 2, stepByLo(T) + 1) : zidx((T) - 2 * stepByLo(T), stepByLo(T)))
 #define I4_STEP(T)                                                                                              \
         {                                                                                                         \
           constexpr int by0 = stepByLo(T), bx0 = (T) - 2 * by0;                                                   \
           constexpr bool two = by0 + 1 <= stepByHi(T);                                                            \
-          constexpr int bx1 = two ? bx0 - 2 : bx0, by1 = two ? by0 + 1 : by0;                                     \
           constexpr int TN = (T) < 9 ? (T) + 1 : 9;                                                               \
+          constexpr int byN = stepByLo(TN), bxN = TN - 2 * byN;                                                   \
+          constexpr int offT = TILE_STRIDE * 4 * by0 + 4 * bx0;                                                   \
           const bool act = mine && (two || ch == 0);                                                              \
-          const int bx = ch ? bx1 : bx0, by = ch ? by1 : by0;                                                     \
-          const int org = tOrg + TILE_STRIDE * 4 * by + 4 * bx - 1;  /* block origin - one row - one column */    \
-          const unsigned mN = min(((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu, 11u);          \
-          const u32x2 enN = wv::lds_u64(entB + 64 * (int)mN);                                                     \
-          const unsigned rrN = wv::lds_u32(resB + 32 * (ch ? I4_BLK(TN, 1) : I4_BLK(TN, 0)));                     \
-          const int a0 = (int)wv::lds_u8(org + (int)((en.x >> 8) & 0xffu)), a1 = (int)wv::lds_u8(org + (int)((en.x >> 16) & 0xffu)); \
-          const int a2 = (int)wv::lds_u8(org + (int)(en.x >> 24));                                                \
-          const int b0 = (int)wv::lds_u8(org + (int)((en.y >> 8) & 0xffu)), b1 = (int)wv::lds_u8(org + (int)((en.y >> 16) & 0xffu)); \
-          const int b2 = (int)wv::lds_u8(org + (int)(en.y >> 24));                                                \
-          const unsigned top = wv::lds_u32(org + 1);                                                              \
-          const int l0 = (int)wv::lds_u8(org + TILE_STRIDE), l1 = (int)wv::lds_u8(org + 2 * TILE_STRIDE);         \
-          const int l2 = (int)wv::lds_u8(org + 3 * TILE_STRIDE), l3r = (int)wv::lds_u8(org + 4 * TILE_STRIDE);     \
+          const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                    \
+          const u32x2 enN = wv::lds_u64(entB + (int)mN);                                                          \
+          const unsigned rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                          \
+          const int a0 = (int)wv::lds_u8(orgB + (int)((en.x >> 8) & 0xffu) + offT);                               \
+          const int a1 = (int)wv::lds_u8(orgB + (int)((en.x >> 16) & 0xffu) + offT);                              \
+          const int a2 = (int)wv::lds_u8(orgB + (int)(en.x >> 24) + offT);                                        \
+          const int b0 = (int)wv::lds_u8(orgB + (int)((en.y >> 8) & 0xffu) + offT);                               \
+          const int b1 = (int)wv::lds_u8(orgB + (int)((en.y >> 16) & 0xffu) + offT);                              \
+          const int b2 = (int)wv::lds_u8(orgB + (int)(en.y >> 24) + offT);                                        \
+          const unsigned top = wv::lds_u32(orgB + offT + 1);                                                      \
+          const int l0 = (int)wv::lds_u8(orgB + offT + TILE_STRIDE), l1 = (int)wv::lds_u8(orgB + offT + 2 * TILE_STRIDE); \
+          const int l2 = (int)wv::lds_u8(orgB + offT + 3 * TILE_STRIDE), l3r = (int)wv::lds_u8(orgB + offT + 4 * TILE_STRIDE); \
           /* (the last load issued: the compiler must not sink the DC samples' loads into a branch of their own) */ \
           const int l3 = wv::opaque(l3r);                                                                         \
           int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                       \
           int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                       \
           {                                                                                                       \
-            /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch) */ \
-            const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA;                                             \
+            /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch). */ \
+            /* Availability of the round's blocks: (bx0, by0) for ch = 0, (bx0 - 2, by0 + 1) for ch = 1 */        \
+            const bool topAv = by0 > 0 ? true : chOrB;                                                            \
+            const bool leftAv = two ? (bx0 == 2 ? nchOrA : true) : (bx0 > 0 ? true : mbA);                        \
             const int sm = (topAv ? (int)wv::sad4(top) : 0) + (leftAv ? l0 + l1 + l2 + l3 : 0);                   \
-            const int both = (topAv && leftAv) ? 1 : 0;                                                           \
-            int dc = (sm + 2 + 2 * both) >> (2 + both);                                                           \
+            /* one sum alone counts twice: (sm + 2) >> 2 == (2 * sm + 4) >> 3 */                                  \
+            int dc = ((sm << ((topAv && leftAv) ? 0 : 1)) + 4) >> 3;                                              \
             if (!topAv && !leftAv) dc = 128;                                                                      \
             if (en.x & 32u) pa = pb = dc;                                                                         \
           }                                                                                                       \
           const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));              \
-          if (act) wv::lds_st16(org + TILE_STRIDE * (py + 1) + 1 + px, o);                                        \
+          if (act) wv::lds_st16(stB + offT, o);                                                                   \
           en = enN;                                                                                               \
           rr = rrN;                                                                                               \
           wv::wave_sync();                                                                                        \
         }
         I4_STEP(0) I4_STEP(1) I4_STEP(2) I4_STEP(3) I4_STEP(4) I4_STEP(5) I4_STEP(6) I4_STEP(7) I4_STEP(8) I4_STEP(9)
-#undef I4_BLK
 #undef I4_STEP
       }
 
@@ -1419,7 +1429,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           const int bx = b8 & 1, by = b8 >> 1;
           const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA, tlAv = topAv && leftAv;
           const bool trAv = b8 == 0 ? mbB : b8 == 1 ? mbC : b8 == 2;
-          const int mode = min((int)((modes4 >> (8 * b8)) & 0xffu), 8);
+          const int mode = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
           const int org8 = tile + TILE_STRIDE * (8 * by) + 8 + 16 * slot + 8 * bx;  // row y = -1, x = 0 of the block
           // raw edge samples k = i and k = i + 16 (top-right replaced by T7 when unavailable)
           auto eaddr = [&](int k) -> int {
@@ -1476,7 +1486,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
               pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
             }
           }
-          const u32x2 rr = wv::lds_u64(resBuf + 512 * g + 32 * (4 * b8 + 2 * (py >> 2) + (x0 >> 2)) + 8 * (py & 3));
+          const u32x2 rr = wv::lds_u64(resBuf + 512 * g + 32 * (4 * (2 * by + (py >> 2)) + 2 * bx + (x0 >> 2)) + 8 * (py & 3));
           const unsigned o = recon_row(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16), rr.x, rr.y);
           if (mine) wv::lds_st32(org8 + TILE_STRIDE * (py + 1) + x0, o);
           wv::wave_sync();
