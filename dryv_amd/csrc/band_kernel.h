@@ -80,7 +80,7 @@ constexpr int CW = 8 * NSC;      // chroma staging: bytes per pixel row
 // FRONT -> BACK, double-buffered by the parity of the team's global step count
 constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [4 * by + bx][y][x]
 constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       8 x the Intra4x4 table row per chain step and block half (always a multiple of 8)
-constexpr int S_INFO = 4288;     // u32 [2][8]              kinds of the 4 macroblocks, Intra16x16 modes, task, step
+constexpr int S_INFO = 4288;     // u32 [2][8]              kinds of the 4 macroblocks, Intra16x16 modes, task, step, parity, chain rounds with a DC block
 constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2] (global step count + 1 of the record in / consumed from the
                                  //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks)
 constexpr int F_READY = 0, F_FREE = 8, F_TASKS = 16, F_HEAD = 32, F_TAILC = 36;
@@ -777,6 +777,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         wv::lds_st32(ts + S_INFO + 32 * buf + 16, task);
         wv::lds_st32(ts + S_INFO + 32 * buf + 20, (unsigned)s);
         wv::lds_st32(ts + S_INFO + 32 * buf + 24, seq & 1u);
+        wv::lds_st32(ts + S_INFO + 32 * buf + 28, 0u);  // rounds of the block chain that have a DC block: see below
       }
       // what was fetched from the band above goes into row 0's rings (BACK's luma ring, the modes ring): at step 0 now
       // (macroblock 0 is this step's neighbour B), otherwise behind the mode derivation, which hides the fetch
@@ -833,6 +834,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           const int t = rbx + 2 * rby;
           const int hh = rby != stepByLo(t) ? 1 : 0;
           wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + 12 * hh + t, (unsigned)(8 * Mp));  // (the table row's offset)
+          // BACK skips the DC arithmetic (and its samples) in the rounds where no block of the step is predicted DC
+          if (valid && Mp == 2) wv::lds_or32(ts + S_INFO + 32 * buf + 28, 1u << t);
         } else if (is8) {
           Mcur = M;
           if (((rbx | rby) & 1) == 0) wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + mzb, (unsigned)(8 * M));  // BACK: modes of blocks 0..3 (x 8: see S_MSEQ)
@@ -1368,14 +1371,18 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
         u32x2 en = wv::lds_u64(entB + (int)(sq0 & 0xffu));
         unsigned rr = wv::lds_u32(resB);
-#define I4_STEP(T)                                                                                              \
+        const unsigned dcRounds = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 28));
+#define I4_BODY(T, DC)                                                                                           \
         {                                                                                                         \
-          constexpr int by0 = stepByLo(T), bx0 = (T) - 2 * by0;                                                   \
-          constexpr bool two = by0 + 1 <= stepByHi(T);                                                            \
-          constexpr int TN = (T) < 9 ? (T) + 1 : 9;                                                               \
-          constexpr int byN = stepByLo(TN), bxN = TN - 2 * byN;                                                   \
-          constexpr int offT = TILE_STRIDE * 4 * by0 + 4 * bx0;                                                   \
-          const bool act = mine && (two || ch == 0);                                                              \
+          /* (the DC samples first: the two bodies then share no leading code the compiler could hoist above the */ \
+          /* branch, which would put these loads behind the wait for the others: a second LDS round trip) */     \
+          unsigned top = 0;                                                                                       \
+          int l0 = 0, l1 = 0, l2 = 0, l3 = 0;                                                                     \
+          if (DC) {                                                                                               \
+            top = wv::lds_u32(orgB + offT + 1);                                                                   \
+            l0 = (int)wv::lds_u8(orgB + offT + TILE_STRIDE), l1 = (int)wv::lds_u8(orgB + offT + 2 * TILE_STRIDE); \
+            l2 = (int)wv::lds_u8(orgB + offT + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(orgB + offT + 4 * TILE_STRIDE); \
+          }                                                                                                       \
           const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                    \
           const u32x2 enN = wv::lds_u64(entB + (int)mN);                                                          \
           const unsigned rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                          \
@@ -1384,15 +1391,10 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           const int a2 = (int)wv::lds_u8(orgB + (int)(en.x >> 24) + offT);                                        \
           const int b0 = (int)wv::lds_u8(orgB + (int)((en.y >> 8) & 0xffu) + offT);                               \
           const int b1 = (int)wv::lds_u8(orgB + (int)((en.y >> 16) & 0xffu) + offT);                              \
-          const int b2 = (int)wv::lds_u8(orgB + (int)(en.y >> 24) + offT);                                        \
-          const unsigned top = wv::lds_u32(orgB + offT + 1);                                                      \
-          const int l0 = (int)wv::lds_u8(orgB + offT + TILE_STRIDE), l1 = (int)wv::lds_u8(orgB + offT + 2 * TILE_STRIDE); \
-          const int l2 = (int)wv::lds_u8(orgB + offT + 3 * TILE_STRIDE), l3r = (int)wv::lds_u8(orgB + offT + 4 * TILE_STRIDE); \
-          /* (the last load issued: the compiler must not sink the DC samples' loads into a branch of their own) */ \
-          const int l3 = wv::opaque(l3r);                                                                         \
+          const int b2 = wv::opaque((int)wv::lds_u8(orgB + (int)(en.y >> 24) + offT));                            \
           int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                       \
           int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                       \
-          {                                                                                                       \
+          if (DC) {                                                                                               \
             /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch). */ \
             /* Availability of the round's blocks: (bx0, by0) for ch = 0, (bx0 - 2, by0 + 1) for ch = 1 */        \
             const bool topAv = by0 > 0 ? true : chOrB;                                                            \
@@ -1407,10 +1409,22 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           if (act) wv::lds_st16(stB + offT, o);                                                                   \
           en = enN;                                                                                               \
           rr = rrN;                                                                                               \
+        }
+#define I4_STEP(T)                                                                                              \
+        {                                                                                                         \
+          constexpr int by0 = stepByLo(T), bx0 = (T) - 2 * by0;                                                   \
+          constexpr bool two = by0 + 1 <= stepByHi(T);                                                            \
+          constexpr int TN = (T) < 9 ? (T) + 1 : 9;                                                               \
+          constexpr int byN = stepByLo(TN), bxN = TN - 2 * byN;                                                   \
+          constexpr int offT = TILE_STRIDE * 4 * by0 + 4 * bx0;                                                   \
+          const bool act = mine && (two || ch == 0);                                                              \
+          /* (wave-uniform: FRONT marked the rounds in which some block of the step is predicted DC) */           \
+          if (dcRounds & (1u << (T))) I4_BODY(T, true) else I4_BODY(T, false)                                     \
           wv::wave_sync();                                                                                        \
         }
         I4_STEP(0) I4_STEP(1) I4_STEP(2) I4_STEP(3) I4_STEP(4) I4_STEP(5) I4_STEP(6) I4_STEP(7) I4_STEP(8) I4_STEP(9)
 #undef I4_STEP
+#undef I4_BODY
       }
 
       // ================= luma, Intra8x8 (8.3.2, pred8x8.rs:152-696): four serial blocks ============================

@@ -55,6 +55,7 @@ WV void lds_st8(int a, unsigned v) { *WV_LDS(uint8_t, a) = (uint8_t)v; }
 WV void lds_st16(int a, unsigned v) { *WV_LDS(uint16_t, a) = (uint16_t)v; }
 WV void lds_st32(int a, unsigned v) { *WV_LDS(unsigned, a) = v; }
 WV void lds_st64(int a, u32x2 v) { *WV_LDS(u32x2, a) = v; }
+WV void lds_or32(int a, unsigned v) { __hip_atomic_fetch_or(WV_LDS(unsigned, a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV void lds_st128(int a, u32x4 v) { *WV_LDS(u32x4, a) = v; }
 
 // ---- VALU helpers -------------------------------------------------------------------------------------
@@ -222,6 +223,7 @@ WV void lds_st8(int a, unsigned v) { emu_lds_check(a, 1); g_emu.lds[a] = (uint8_
 WV void lds_st16(int a, unsigned v) { emu_lds_check(a, 2); *(uint16_t*)(g_emu.lds + a) = (uint16_t)v; }
 WV void lds_st32(int a, unsigned v) { emu_lds_check(a, 4); *(unsigned*)(g_emu.lds + a) = v; }
 WV void lds_st64(int a, u32x2 v) { emu_lds_check(a, 8); memcpy(g_emu.lds + a, &v, 8); }
+WV void lds_or32(int a, unsigned v) { emu_lds_check(a, 4); *(unsigned*)(g_emu.lds + a) |= v; }
 WV void lds_st128(int a, u32x4 v) { emu_lds_check(a, 16); if (a & 15) { fprintf(stderr, "emu: unaligned b128 st %d\n", a); abort(); } memcpy(g_emu.lds + a, &v, 16); }
 
 WV unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
