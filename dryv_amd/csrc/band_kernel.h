@@ -248,6 +248,7 @@ WV void idct4x4(const u32x4 c0, const u32x4 c1, const u32x4 l0, const u32x4 l1, 
     d[k] = ((((T)(c * l)) * ((T)1 << shl)) + (T)rnd) >> shr;   // |c * l| < 2^15 * 7395 fits int32
   }
   if (useDc) d[0] = dcVal;
+  d[0] += 32;  // the rounding term of :183-187: element (0,0) reaches every output with weight 1 and through no shift
   T f[4][4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {  // row butterflies (transform.rs:159-169)
@@ -262,10 +263,10 @@ WV void idct4x4(const u32x4 c0, const u32x4 c1, const u32x4 l0, const u32x4 l1, 
 #pragma unroll
   for (int c = 0; c < 4; c++) {  // column butterflies (:171-181), rounding (:183-187)
     const T g0 = f[0][c] + f[2][c], g1 = f[0][c] - f[2][c], g2 = (f[1][c] >> 1) - f[3][c], g3 = f[1][c] + (f[3][c] >> 1);
-    h[0][c] = (g0 + g3 + 32) >> 6;
-    h[1][c] = (g1 + g2 + 32) >> 6;
-    h[2][c] = (g1 - g2 + 32) >> 6;
-    h[3][c] = (g0 - g3 + 32) >> 6;
+    h[0][c] = (g0 + g3) >> 6;
+    h[1][c] = (g1 + g2) >> 6;
+    h[2][c] = (g1 - g2) >> 6;
+    h[3][c] = (g0 - g3) >> 6;
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -1045,7 +1046,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         const unsigned tw = wv::lds_u32(ringP + RINGC_ENT * (xC & 3) + 4 * ccx);
         const unsigned lw = wv::lds_u32(leftC + 4 * ccy);
         unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
-        if (cmode == 0) {
+        if (wv::any(chromaLane && cmode == 0)) {
           const int st = (int)wv::sad4(tw), sl = (int)wv::sad4(lw);
           // trans_chroma.rs:168-286 incl. quirk Q2 (`> 0` where the spec means "available"):
           //   blocks (0,0),(4,4): both -> 8-sample mean; left only -> left; top only needs every top sample > 0
@@ -1057,7 +1058,9 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
           const int vTR = mbBC ? vT : l3 ? vL : 128;
           const int vBL = l3 ? vL : t3 ? vT : 128;
           const int v = ccx == ccy ? vDiag : ccx == 1 ? vTR : vBL;
-          src = (unsigned)v * 0x01010101u;
+          if (cmode == 0) src = (unsigned)v * 0x01010101u;
+        }
+        if (cmode == 0) {
         } else if (cmode == 1) {  // horizontal (zero without neighbour A: quirk Q4)
           if (!mbAC) src = 0;
         } else if (cmode == 2) {  // vertical
@@ -1262,7 +1265,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
         const unsigned lw = wv::lds_u32(ts + S_LEFTY + 16 * g + 4 * zby);
         unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
-        {
+        if (wv::any(valid && kind == 2 && i16mode == 2)) {
           // DC: one reduction over the row group of the available sums
           int sm = ((zby == 0 && mbB) ? (int)wv::sad4(tw) : 0) + ((zbx == 0 && mbA) ? (int)wv::sad4(lw) : 0);
           sm += xor8(sm);
