@@ -55,11 +55,13 @@ constexpr int T_QPC = 192;    // u8  [2][52]    QP'c for Cb / Cr as a function o
 constexpr int T_THR4 = 304;   // u16 [52]
 constexpr int T_THR8 = 408;   // u16 [52]
 constexpr int T_T4E = 512;    // u32 [8][12][2] Intra4x4 entries [pixel pair][mode][pixel]
-constexpr int T_END = 1280;
-constexpr int T_LS8 = 1280;   // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
-constexpr int T_T8 = 2048;    // u8  [9][64]    Intra8x8 table [mode][y*8+x]: index on the filtered edge | value kind << 5
-constexpr int T_ZZ8 = 2624;   // u8  [64]       8x8 list index -> 2 * raster position
-constexpr int T_END_I8 = 2688;
+constexpr int T_LS4Q = 1280;  // u16 [52][16]   per qp: LevelScale4x4 << max(qp/6 - 4, 0) in list order, 0xFFFF where that needs 17 bits
+constexpr int T_LSMAX = 2944; // u16 [52]       per qp: the largest entry of its T_LS4Q row
+constexpr int T_END = 3072;
+constexpr int T_LS8 = 3072;   // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
+constexpr int T_T8 = 3840;    // u8  [9][64]    Intra8x8 table [mode][y*8+x]: index on the filtered edge | value kind << 5
+constexpr int T_ZZ8 = 4416;   // u8  [64]       8x8 list index -> 2 * raster position
+constexpr int T_END_I8 = 4480;
 
 // ---- per-team scratch in LDS (byte offsets from the team's base) ---------------------------------------------
 // Output staging: a row's pixels are flushed to global memory NSY (luma) / NSC (chroma) macroblocks at a time, as
@@ -136,6 +138,11 @@ constexpr unsigned TASK_END = 0xFFFFFFFFu;
     phAcc[k] += now_ - phT;                                       \
     phT = now_;                                                   \
   } while (0)
+#elif defined(DRYV_BAND_MARK) && !defined(DRYV_EMU)
+// analysis only (tools/band_static.py): phase boundaries as comments in the assembly, to count instructions between them
+#define PH_STR2(x) #x
+#define PH_STR(x) PH_STR2(x)
+#define PH(k) asm volatile("; DRYV_MARK " PH_STR(__LINE__) " " #k ::: "memory")
 #else
 #define PH(k) do { } while (0)
 #endif
@@ -200,6 +207,17 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
   for (int k = tid; k < 52; k += nthreads) {
     wv::lds_st16(ldsBase + T_THR4 + 2 * k, P.thr4[k]);
     wv::lds_st16(ldsBase + T_THR8 + 2 * k, P.thr8[k]);
+  }
+  for (int k = tid; k < 832; k += nthreads) {
+    const int qp = k >> 4, qd = qp / 6, qm = qp - 6 * qd;
+    const unsigned v = (unsigned)P.ls4z[16 * qm + (k & 15)] << (qd > 4 ? qd - 4 : 0);
+    wv::lds_st16(ldsBase + T_LS4Q + 2 * k, v > 0xFFFFu ? 0xFFFFu : v);
+  }
+  for (int qp = tid; qp < 52; qp += nthreads) {
+    const int qd = qp / 6, qm = qp - 6 * qd;
+    unsigned m = 0;
+    for (int k = 0; k < 16; k++) m = max(m, (unsigned)P.ls4z[16 * qm + k] << (qd > 4 ? qd - 4 : 0));
+    wv::lds_st16(ldsBase + T_LSMAX + 2 * qp, m > 0xFFFFu ? 0xFFFFu : m);
   }
   for (int k = tid; k < 192; k += nthreads) {
     // entry of (table row m, pixel pair p, pixel e): shift | DC flag << 5 | three tile offsets relative to
@@ -324,6 +342,84 @@ WV void idct4x4_wide(const u32x4 c0, const u32x4 c1, int lsAddr, int shl, int rn
   }
 }
 
+// ---- the same transform on packed 16-bit pairs, for blocks that provably fit -----------------------------------
+// Every value the two passes form is a sum of the dequantised entries with weights of magnitude <= 1 (|x >> 1| <= |x|),
+// so nothing exceeds B = sum |d_k| + 32 <= sum |c_k| * max LS' + |dc| + 32 with LS' = LS << max(qp/6 - 4, 0): when
+// B < 2^15 the wrap-around 16-bit arithmetic below is exact, and so are the 16-bit products c * LS' (+ rnd). A step
+// whose 64 blocks all pass (block_fits16) takes this path; one block that does not sends the wave through idct4x4<int>.
+// sum of |c| over the block's 16 entries (entry 0 excluded when it is not a coefficient of this block)
+WV unsigned sum_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
+  const unsigned b = 0x80008000u;  // c ^ 0x8000 = c + 32768 as an unsigned half: |that - 32768| = |c|
+  unsigned a = wv::sad_u16((skip0 ? c0.x & 0xffff0000u : c0.x) ^ b, b, 0u);
+  a = wv::sad_u16(c0.y ^ b, b, a);
+  a = wv::sad_u16(c0.z ^ b, b, a);
+  a = wv::sad_u16(c0.w ^ b, b, a);
+  a = wv::sad_u16(c1.x ^ b, b, a);
+  a = wv::sad_u16(c1.y ^ b, b, a);
+  a = wv::sad_u16(c1.z ^ b, b, a);
+  return wv::sad_u16(c1.w ^ b, b, a);
+}
+WV bool block_fits16(const u32x4 c0, const u32x4 c1, int ldsBase, int qp, bool useDc, long long dcVal) {
+  const unsigned sa = min(sum_abs16(c0, c1, useDc), 32768u);            // (<= 2^15: the product below fits 32 bits)
+  unsigned bound = sa * wv::lds_u16(ldsBase + T_LSMAX + 2 * qp);
+  if (useDc) {
+    const int dc = (int)dcVal;
+    if ((long long)dc != dcVal || dc > 32767 || dc < -32767) return false;
+    bound += (unsigned)(dc < 0 ? -dc : dc);
+  }
+  return bound <= 32700u;
+}
+// entries za (low half) and zb (high half) of the list, as one pair
+template <int ZA, int ZB>
+WV unsigned zz_pair(const unsigned z[8]) {
+  if ((ZA >> 1) == (ZB >> 1) && (ZA & 1) == 0 && (ZB & 1) == 1) return z[ZA >> 1];
+  constexpr unsigned sel = (unsigned)(2 * (ZA & 1)) | ((unsigned)(2 * (ZA & 1) + 1) << 8) | ((unsigned)(4 + 2 * (ZB & 1)) << 16) |
+                           ((unsigned)(5 + 2 * (ZB & 1)) << 24);
+  return wv::perm(z[ZB >> 1], z[ZA >> 1], sel);
+}
+// one butterfly (transform.rs:159-181) on four pairs
+WV void butterfly_pk(const unsigned m[4], unsigned f[4]) {
+  const unsigned e0 = wv::pk_add(m[0], m[2]), e1 = wv::pk_sub(m[0], m[2]);
+  const unsigned e2 = wv::pk_sub(wv::pk_ashr1(m[1]), m[3]), e3 = wv::pk_add(m[1], wv::pk_ashr1(m[3]));
+  f[0] = wv::pk_add(e0, e3);
+  f[1] = wv::pk_add(e1, e2);
+  f[2] = wv::pk_sub(e1, e2);
+  f[3] = wv::pk_sub(e0, e3);
+}
+// lq0/lq1: the qp's T_LS4Q row. rnd / shr as in idct4x4 (both 0 from qp 24 up: the shift is in the table).
+WV void idct4x4_pk16(const u32x4 c0, const u32x4 c1, const u32x4 lq0, const u32x4 lq1, int rnd, int shr, bool useDc, int dcVal,
+                     unsigned out[8]) {
+  const unsigned cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const unsigned lw[8] = {lq0.x, lq0.y, lq0.z, lq0.w, lq1.x, lq1.y, lq1.z, lq1.w};
+  const unsigned rnd2 = (unsigned)rnd * 0x10001u, shr2 = (unsigned)shr * 0x10001u;
+  unsigned z[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) z[k] = wv::pk_mad(cw[k], lw[k], rnd2);
+  if (wv::any(shr != 0)) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) z[k] = wv::pk_ashr(z[k], shr2);
+  }
+  if (useDc) z[0] = (z[0] & 0xffff0000u) | ((unsigned)dcVal & 0xffffu);
+  z[0] = wv::pk_add(z[0], 32u);  // the rounding term of :183-187, through element (0,0) (see idct4x4)
+  // rows (0 | 3) and (1 | 2) as pairs: two of the eight are list neighbours already
+  const unsigned ra[4] = {zz_pair<ZZ4IDX(0, 0), ZZ4IDX(3, 0)>(z), zz_pair<ZZ4IDX(0, 1), ZZ4IDX(3, 1)>(z),
+                          zz_pair<ZZ4IDX(0, 2), ZZ4IDX(3, 2)>(z), zz_pair<ZZ4IDX(0, 3), ZZ4IDX(3, 3)>(z)};
+  const unsigned rb[4] = {zz_pair<ZZ4IDX(1, 0), ZZ4IDX(2, 0)>(z), zz_pair<ZZ4IDX(1, 1), ZZ4IDX(2, 1)>(z),
+                          zz_pair<ZZ4IDX(1, 2), ZZ4IDX(2, 2)>(z), zz_pair<ZZ4IDX(1, 3), ZZ4IDX(2, 3)>(z)};
+  unsigned fa[4], fb[4];   // fa[c] = f[0][c] | f[3][c] << 16, fb[c] = f[1][c] | f[2][c] << 16
+  butterfly_pk(ra, fa);
+  butterfly_pk(rb, fb);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {  // columns 2q | 2q+1 as pairs
+    const unsigned col[4] = {wv::perm(fa[2 * q + 1], fa[2 * q], 0x05040100u), wv::perm(fb[2 * q + 1], fb[2 * q], 0x05040100u),
+                             wv::perm(fb[2 * q + 1], fb[2 * q], 0x07060302u), wv::perm(fa[2 * q + 1], fa[2 * q], 0x07060302u)};
+    unsigned h[4];
+    butterfly_pk(col, h);
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[2 * r + q] = wv::pk_ashr6(h[r]);
+  }
+}
+
 // largest |c| over the block's entries (entry 0 excluded when it is not a coefficient of this block); 32768 for -32768
 WV int max_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
   const unsigned w0 = skip0 ? c0.x & 0xffff0000u : c0.x;
@@ -338,11 +434,17 @@ WV int max_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
 // takes the 64-bit path (wave-uniform branch). Fast build: the batch is flagged (status bit 1) and the host re-runs it
 // with the WIDE build before anything is reported -- the fast kernel carries no 64-bit code, which would cost it its
 // register budget; no conformant stream ever takes this route.
+// unused: this lane's result is not needed (an Intra8x8 macroblock's lanes): it must not keep the wave off the packed path.
 template <bool WIDE>
-WV void residual_pass(const u32x4 c0, const u32x4 c1, int lsAddr, int qp, bool useDc, long long dcVal, int thr,
-                      unsigned* status, unsigned out[8]) {
+WV void residual_pass(const u32x4 c0, const u32x4 c1, int ldsBase, int lsAddr, int qp, bool useDc, long long dcVal, int thr,
+                      bool unused, unsigned* status, unsigned out[8]) {
   const int qd = (qp * 43) >> 8;
   const int shl = max(qd - 4, 0), shr = max(4 - qd, 0), rnd = qd < 4 ? (1 << (3 - qd)) : 0;
+  if (!wv::any(!unused && !block_fits16(c0, c1, ldsBase, qp, useDc, dcVal))) {
+    const u32x4 lq0 = wv::lds_u128(ldsBase + T_LS4Q + 32 * qp), lq1 = wv::lds_u128(ldsBase + T_LS4Q + 32 * qp + 16);
+    idct4x4_pk16(c0, c1, lq0, lq1, rnd, shr, useDc, (int)dcVal, out);
+    return;
+  }
   bool big = false;
   if (wv::any(thr != 0xFFFF)) big = thr != 0xFFFF && max_abs16(c0, c1, useDc) > thr;
   if (useDc && (dcVal > (1ll << 26) || dcVal < -(1ll << 26))) big = true;
@@ -696,7 +798,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         const int qm = qp - 6 * ((qp * 43) >> 8);
         // (an Intra8x8 lane's result of this pass is not used: it must not raise the 4x4 overflow flag either)
         const int thr4 = (HAS_I8 && kind == 1) ? 0xFFFF : (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp);
-        residual_pass<WIDE>(cA0, cA1, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, thr4, A.status, rA);
+        residual_pass<WIDE>(cA0, cA1, ldsBase, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, thr4, HAS_I8 && kind == 1, A.status, rA);
         // Intra8x8 macroblocks: their lanes' rA becomes 16 residuals of one column per 8x8 block pass (residual8x8)
         if (HAS_I8 && wv::any(valid && kind == 1)) {
           unsigned r8[8];
@@ -1027,7 +1129,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         v = (cblk & 2) ? o - v : v + o;
         const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
         const long long dcC = (((long long)v * ls00) * (1ll << qd)) >> 5;   // trans_chroma.rs:413
-        residual_pass<WIDE>(cB0, cB1, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), A.status, rB);
+        residual_pass<WIDE>(cB0, cB1, ldsBase, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), false, A.status, rB);
         if (wv::any(kindC == 3)) {
 #pragma unroll
           for (int k = 0; k < 8; k++) rB[k] = kindC == 3 ? 0u : rB[k];

@@ -71,6 +71,22 @@ WV unsigned pk_add(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
 }
 WV unsigned pk_ashr5(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 5)); }
+WV unsigned pk_ashr1(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 1)); }
+WV unsigned pk_ashr6(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 6)); }
+// per-half arithmetic shift right by the low four bits of the matching half of sh (v_pk_ashrrev_i16)
+WV unsigned pk_ashr(unsigned a, unsigned sh) {
+  return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> (__builtin_bit_cast(s16x2, sh) & (s16x2)15)));
+}
+WV unsigned pk_sub(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
+}
+// per half: low 16 bits of a * b + c (v_pk_mad_u16; the same bits for signed and unsigned operands)
+WV unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c)));
+}
+// |a.lo - b.lo| + |a.hi - b.hi| + acc on unsigned halves (v_sad_u16)
+WV unsigned sad_u16(unsigned a, unsigned b, unsigned acc) { return __builtin_amdgcn_sad_u16(a, b, acc); }
 WV unsigned pk_max(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
@@ -259,6 +275,20 @@ WV unsigned pk_add(unsigned a, unsigned b) { return ((a + b) & 0xffff) | (((a >>
 WV unsigned pk_ashr5(unsigned a) {
   const int lo = (int)(int16_t)a >> 5, hi = (int)(int16_t)(a >> 16) >> 5;
   return ((unsigned)lo & 0xffff) | ((unsigned)hi << 16);
+}
+WV unsigned pk_ashr(unsigned a, unsigned sh) {
+  const int lo = (int)(int16_t)a >> (sh & 15), hi = (int)(int16_t)(a >> 16) >> ((sh >> 16) & 15);
+  return ((unsigned)lo & 0xffff) | ((unsigned)hi << 16);
+}
+WV unsigned pk_ashr1(unsigned a) { return pk_ashr(a, 0x00010001u); }
+WV unsigned pk_ashr6(unsigned a) { return pk_ashr(a, 0x00060006u); }
+WV unsigned pk_sub(unsigned a, unsigned b) { return ((a - b) & 0xffff) | (((a >> 16) - (b >> 16)) << 16); }
+WV unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
+  return (((a & 0xffff) * (b & 0xffff) + (c & 0xffff)) & 0xffff) | ((((a >> 16) * (b >> 16) + (c >> 16)) & 0xffff) << 16);
+}
+WV unsigned sad_u16(unsigned a, unsigned b, unsigned acc) {
+  const int dl = (int)(a & 0xffff) - (int)(b & 0xffff), dh = (int)(a >> 16) - (int)(b >> 16);
+  return acc + (unsigned)(dl < 0 ? -dl : dl) + (unsigned)(dh < 0 ? -dh : dh);
 }
 WV unsigned sat_pk_u8(unsigned pair) {
   const int lo = (int16_t)pair, hi = (int16_t)(pair >> 16);
