@@ -15,7 +15,7 @@ import pytest
 
 import oracle
 from dryv_amd import abi, synth
-from util import first_mismatch
+from util import first_mismatch, packed16_bound_batches
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import emu  # noqa: E402
@@ -155,3 +155,11 @@ def test_emulated_fast_path_at_its_exactness_bound():
                                                                         else rng.choice([-1, 1], size=384))
                     co[a] = sign * lim
                 check(fp, 1, mbs, co.astype(np.int16))
+
+
+def test_emulated_packed16_path_at_its_bound():
+    """4x4 residuals run on packed 16-bit pairs when every block of a step has sum |c| * max LS' (+ |dc|) <= 32700; a block
+    above it sends the step through the 32-bit path. Blocks exactly at the bound and one above it, every qp class."""
+    fp = abi.make_frame_params(5, 4)
+    for qp, bump, mbs, co in packed16_bound_batches(fp, synth):
+        check(fp, 1, mbs, co)

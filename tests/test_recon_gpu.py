@@ -13,7 +13,7 @@ import pytest
 
 import oracle
 from dryv_amd import abi, synth, Frame, ReconError
-from util import first_mismatch, make_coeffs, make_mb, split_planes
+from util import first_mismatch, make_coeffs, make_mb, split_planes, packed16_bound_batches
 
 pytestmark = pytest.mark.gpu
 
@@ -503,3 +503,12 @@ def test_exactness_bound_adversarial(recon_ctx):
                                                                         else rng.choice([-1, 1], size=384))
                     co[a] = sign * lim
                 assert_parity(recon_ctx, fp, 2, mbs, co.astype(np.int16))
+
+
+@pytest.mark.gpu
+def test_packed16_residual_path_at_its_bound(recon_ctx):
+    """The band kernel's packed 16-bit residual path: every luma block's sum |c| at the bound that admits it, and one
+    above (the step then takes the 32-bit path). Bit-exact against the oracle's 64-bit arithmetic either way."""
+    fp = abi.make_frame_params(9, 6)
+    for qp, bump, mbs, co in packed16_bound_batches(fp, synth, frames=2):
+        assert_parity(recon_ctx, fp, 2, mbs, co)

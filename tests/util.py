@@ -55,3 +55,49 @@ def first_mismatch(a, b, W, H):
         pl, y, x, mbw = "Cr", o // (8 * W), o % (8 * W), 8
     return "%d bytes differ; first: frame %d plane %s x=%d y=%d (mb %d,%d) got %d want %d" % (
         idx.size, f, pl, x, y, x // mbw, y // mbw, a[i], b[i])
+
+
+V4 = np.array([[10, 16, 13], [11, 18, 14], [13, 20, 16], [14, 23, 18], [16, 25, 20], [18, 29, 23]])
+
+
+def packed16_bound_batches(fp, synth, frames=1, qps=(0, 11, 23, 24, 29, 30, 35, 36, 40, 47, 51)):
+    """Adversarial input for the band kernel's packed 16-bit residual path (flat scaling lists): every luma block's
+    sum of |c| sits exactly AT the bound under which a step takes that path (32700 // max LS'), or one above it, spent on
+    one entry, on all sixteen, on the first row / column, with the sign patterns that maximise the butterflies' growth.
+    Chroma and the Intra16x16 DC terms stay at whatever the generator drew. Yields (qp, bump, mbs, coeffs)."""
+    rng = np.random.default_rng(16)
+    for qp in qps:
+        qd, qm = qp // 6, qp % 6
+        ls_max = (16 * int(V4[qm].max())) << max(qd - 4, 0)
+        lim = 32700 // ls_max
+        for bump in (0, 1):
+            mbs, co = synth.generate(fp, synth.config(i4x4=0.8, i8x8=0.0, coded=1.0, qp=(qp, qp)), 1600 + qp, 0, frames)
+            co = co.astype(np.int64)
+            for a in range(co.shape[0]):
+                if mbs["mb_kind"][a] != 0:
+                    continue
+                for b in range(16):
+                    blk = np.zeros(16, dtype=np.int64)
+                    tot = lim + bump
+                    pat = int(rng.integers(0, 5))
+                    if pat == 0:                                  # everything on one entry
+                        blk[int(rng.integers(0, 16))] = tot
+                    elif pat == 1:                                # spread over all sixteen
+                        blk[:] = tot // 16
+                        blk[0] += tot - blk.sum()
+                    elif pat == 2:                                # the first four list entries
+                        blk[:4] = tot // 4
+                        blk[0] += tot - blk.sum()
+                    elif pat == 3:                                # two entries
+                        k = rng.choice(16, size=2, replace=False)
+                        blk[k[0]] = tot // 2
+                        blk[k[1]] = tot - tot // 2
+                    else:                                         # random split
+                        w = rng.random(16)
+                        blk = np.floor(w / w.sum() * tot).astype(np.int64)
+                        blk[int(rng.integers(0, 16))] += tot - blk.sum()
+                    sgn = int(rng.integers(0, 3))
+                    sign = np.ones(16, dtype=np.int64) if sgn == 0 else (-np.ones(16, dtype=np.int64) if sgn == 1
+                                                                         else rng.choice([-1, 1], size=16))
+                    co[a, 16 * b:16 * b + 16] = np.clip(blk * sign, -32768, 32767)
+            yield qp, bump, mbs, co.astype(np.int16)
