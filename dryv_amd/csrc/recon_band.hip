@@ -40,7 +40,10 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5
   else band::band_chroma<HAS_I8, WIDE>(P, A, ldsBase, ts);
 }
 
-size_t band_lds_bytes(bool hasI8, int teams) { return (size_t)(hasI8 ? band::T_END_I8 : band::T_END) + (size_t)teams * band::team_bytes(hasI8); }
+#ifndef DRYV_BAND_LDS_PAD
+#define DRYV_BAND_LDS_PAD 0   // (tuning: extra LDS per workgroup, to cap the workgroups a CU accepts)
+#endif
+size_t band_lds_bytes(bool hasI8, int teams) { return (size_t)(hasI8 ? band::T_END_I8 : band::T_END) + (size_t)teams * band::team_bytes(hasI8) + DRYV_BAND_LDS_PAD; }
 // The builds that need more registers (8x8 transform: 96 VGPRs; wide: up to 128) run three teams per workgroup at most.
 int band_teams_per_block(bool hasI8, bool wide) { return (hasI8 || wide) ? (band::TEAMS_PER_WG < 3 ? band::TEAMS_PER_WG : 3) : band::TEAMS_PER_WG; }
 int band_blocks_per_cu() { return DRYV_BAND_WGS_PER_CU; }
