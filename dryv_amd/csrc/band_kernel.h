@@ -579,7 +579,7 @@ WV int xor2(int v) { return wv::dppx<DPP_QUAD(2, 3, 0, 1)>(v); }
 // One reconstructed row of 4 pixels: prediction as two u16 pairs, residual as two i16 pairs
 WV unsigned recon_row(unsigned p01, unsigned p23, unsigned r01, unsigned r23) {
   const unsigned a = wv::sat_pk_u8(wv::pk_add_sat(p01, r01)), b = wv::sat_pk_u8(wv::pk_add_sat(p23, r23));
-  return (a & 0xffffu) | (b << 16);
+  return wv::perm(b, a, 0x05040100u);  // bytes 0, 1 of a, then bytes 0, 1 of b
 }
 
 
@@ -588,10 +588,28 @@ struct BandGeo {
   int b, f, r0, nR, gl, nSteps;
   bool hasAbove, hasBelow;
 };
+// Queue order: groups of TASK_GROUP consecutive bands; within a group frame by frame, band after band. A band's
+// predecessor (same frame, band above) always has a smaller number, whatever the group size. 1 = band-major order (band 0
+// of every frame, band 1 of every frame, ...), which ships: larger groups put more bands of fewer pictures in flight
+// (deeper chains of bands following each other) and measured slower on the 300-picture batch: 1.65 ms (1), 1.69 (2),
+// 1.75 (4), 2.01 (8), 2.70 (17 = picture after picture).
+#ifndef DRYV_BAND_TASK_GROUP
+#define DRYV_BAND_TASK_GROUP 1
+#endif
+constexpr int TASK_GROUP = DRYV_BAND_TASK_GROUP;
 WV BandGeo band_geo(unsigned task, int nF, int W, int H) {
   BandGeo G;
-  G.b = (int)(task / (unsigned)nF);
-  G.f = (int)(task - (unsigned)G.b * (unsigned)nF);
+  if (TASK_GROUP == 1) {
+    G.b = (int)(task / (unsigned)nF);
+    G.f = (int)(task - (unsigned)G.b * (unsigned)nF);
+  } else {
+    const unsigned nB = (unsigned)((H + 3) >> 2), perGroup = (unsigned)TASK_GROUP * (unsigned)nF;
+    const unsigned g = task / perGroup, r = task - g * perGroup;
+    const unsigned nb = min((unsigned)TASK_GROUP, nB - g * (unsigned)TASK_GROUP);  // bands in this group (the last may be short)
+    const unsigned f = r / nb;
+    G.f = (int)f;
+    G.b = (int)(g * (unsigned)TASK_GROUP + (r - f * nb));
+  }
   G.r0 = 4 * G.b;
   G.nR = min(4, H - G.r0);
   G.gl = G.nR - 1;  // the band's last row
@@ -907,13 +925,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
         const int Lb = wv::dpp<DPP_ROW_SHL(3)>(Mprev, Mprev);
         const bool unav = (rbx == 0 && !mbA) || (rby == 0 && !mbB);
+        // the neighbours outside the macroblock: A of column 0 (the macroblock to the left), B of row 0 (the ring); 15 = none
+        const int outer = min(rbx == 0 ? (mbA ? Lb : 2) : 15, rby == 0 ? Tb : 15);
         int M = 2;
 #pragma unroll
         for (int itr = 0; itr < 7; itr++) {
-          int Am = wv::dppx<DPP_QUAD(0, 0, 1, 2)>(M);
-          if (rbx == 0) Am = mbA ? Lb : 2;
-          const int Bm = wv::dpp<DPP_ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
-          const int pm = unav ? 2 : min(Am, Bm);
+          int pm = wv::grid_min(outer, M);  // ... and inside it: A for columns 1..3, B for rows 1..3
+          if (unav) pm = 2;
           M = prev ? pm : (rem < pm ? rem : rem + 1);
           if (HAS_I8) {
             const int t = wv::dppx<DPP_QUAD(0, 0, 2, 2)>(M);        // the even column's value

@@ -55,7 +55,11 @@ def main():
     print("task duration (claim -> BACK's last step): mean %.1f us, p10 %.1f, p50 %.1f, p90 %.1f" %
           (dur.mean(), *np.percentile(dur, [10, 50, 90])))
     print("team occupancy: sum of task durations / (teams x span) = %.3f" % (dur.sum() / (len(np.unique(wave)) * end)))
-    band = np.arange(tasks) // n
+    grp = next((int(f.split('=')[1]) for f in flags if f.startswith('-DDRYV_BAND_TASK_GROUP=')), 1)   # band_kernel.h: band_geo
+    t_ = np.arange(tasks)
+    g_, r_ = t_ // (grp * n), t_ % (grp * n)
+    nb_ = np.minimum(grp, nb - g_ * grp)
+    band = g_ * grp + r_ % nb_ if grp > 1 else t_ // n
     print("band: claim mean / first-step mean / last-step mean (us), duration")
     for b in range(nb):
         m = band == b
