@@ -925,13 +925,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
         const int Lb = wv::dpp<DPP_ROW_SHL(3)>(Mprev, Mprev);
         const bool unav = (rbx == 0 && !mbA) || (rby == 0 && !mbB);
-        // the neighbours outside the macroblock: A of column 0 (the macroblock to the left), B of row 0 (the ring); 15 = none
-        const int outer = min(rbx == 0 ? (mbA ? Lb : 2) : 15, rby == 0 ? Tb : 15);
         int M = 2;
 #pragma unroll
         for (int itr = 0; itr < 7; itr++) {
-          int pm = wv::grid_min(outer, M);  // ... and inside it: A for columns 1..3, B for rows 1..3
-          if (unav) pm = 2;
+          int Am = wv::dppx<DPP_QUAD(0, 0, 1, 2)>(M);
+          if (rbx == 0) Am = mbA ? Lb : 2;
+          const int Bm = wv::dpp<DPP_ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
+          const int pm = unav ? 2 : min(Am, Bm);
           M = prev ? pm : (rem < pm ? rem : rem + 1);
           if (HAS_I8) {
             const int t = wv::dppx<DPP_QUAD(0, 0, 2, 2)>(M);        // the even column's value
@@ -1059,6 +1059,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     };
     unsigned kN1 = load_kind(0);  // first record word of this lane's macroblock in the next pair of steps
     unsigned dC = 0;              // ... in the current pair
+    unsigned dEven = 0, dOdd = 0; // ... of the even / the odd step of the current pair, on all 64 lanes
     unsigned rB[8];               // this lane's block residual (current pair)
 #pragma unroll
     for (int k = 0; k < 8; k++) rB[k] = 0;
@@ -1076,25 +1077,32 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       if (evenStep) dC = kN1;
       const int lane = wv::opaque(lane0);
       const int g = lane >> 4, i = lane & 15;                                            // write-out organisation: row g
-      const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;           // lane-per-block, step sL
-      const int ccx = cblk & 1, ccy = cblk >> 1;
-      const int sL = (s & ~1) + (lane >> 5);      // the step this lane's block belongs to
-      const bool chromaLane = sL == s;
+      // residuals: lane = (half of the pair of steps, row gc, plane, block): lanes 32..63 work on the odd step's blocks.
+      // prediction: lane = (half of the block, row gc, plane, block) of THIS step: lanes 32..63 predict rows 2, 3 of the
+      // block whose rows 0, 1 lane - 32 predicts (8 pixels per lane on all 64 lanes)
+      const int gc = (lane >> 3) & 3, cpl = (lane >> 2) & 1, cblk = lane & 3;
+      const int ccx = cblk & 1, ccy = cblk >> 1, half = lane >> 5;
       const int r = r0 + g, rC = r0 + gc;
       const bool mbBC = rC > 0;
-      const int x = s - 2 * g, xC = sL - 2 * gc;
+      const int x = s - 2 * g, xC = s - 2 * gc;
       const bool valid = g < nR && x >= 0 && x < W, validC = gc < nR && xC >= 0 && xC < W;
       const bool mbAC = xC > 0;
       const int slot = x & (NSC - 1), slotC = xC & (NSC - 1);  // staging columns
       const bool needUp = hasAbove && s < W;
       unsigned lineV = 0;
-      // the record checks FRONT makes (it also reports them): an unsupported record reconstructs as zero
-      int kindC = (int)(dC & 0xffu), qpC = (int)(dC >> 24);
-      const int cmode = (int)((dC >> 16) & 0xffu);
-      if (kindC > 2 || (!HAS_I8 && kindC == 1) || qpC > 51 || ((dC >> 8) & 0xffu) > 3u || cmode > 3) {
-        kindC = 3;
-        qpC = 0;
-      }
+      // the record checks FRONT makes (it also reports them): an unsupported record reconstructs as zero.
+      // dC: the residual lane's macroblock (of its step of the pair); dP: the prediction lane's (of this step)
+      auto checked = [&](unsigned d, int& kind, int& qp, int& mode) {
+        kind = (int)(d & 0xffu);
+        qp = (int)(d >> 24);
+        mode = (int)((d >> 16) & 0xffu);
+        if (kind > 2 || (!HAS_I8 && kind == 1) || qp > 51 || ((d >> 8) & 0xffu) > 3u || mode > 3) {
+          kind = 3;
+          qp = 0;
+        }
+      };
+      int kindR, qpR, cmodeR;
+      checked(dC, kindR, qpR, cmodeR);
 
       // ---- hand-off traffic. Publish: the previous step ended with the write-through stores of its last-row
       // macroblock's bottom chroma lines (and the staged row segments); once vmcnt says that everything this wave has
@@ -1138,7 +1146,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       if (evenStep) {
         // chroma DC 2x2 (8.5.11, trans_chroma.rs:369-415) over the four block lanes of a plane, then the AC pass.
         // The LevelScale table is luma's (quirk Q3).
-        const int qc = (int)wv::lds_u8(ldsBase + T_QPC + 52 * cpl + qpC);
+        const int qc = (int)wv::lds_u8(ldsBase + T_QPC + 52 * cpl + qpR);
         const int qd = (qc * 43) >> 8, qm = qc - 6 * qd;
         int v = dcB;
         int o = xor1(v);
@@ -1148,10 +1156,16 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
         const long long dcC = (((long long)v * ls00) * (1ll << qd)) >> 5;   // trans_chroma.rs:413
         residual_pass<WIDE>(cB0, cB1, ldsBase, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), false, A.status, rB);
-        if (wv::any(kindC == 3)) {
+        if (wv::any(kindR == 3)) {
 #pragma unroll
-          for (int k = 0; k < 8; k++) rB[k] = kindC == 3 ? 0u : rB[k];
+          for (int k = 0; k < 8; k++) rB[k] = kindR == 3 ? 0u : rB[k];
         }
+        // hand the halves over (v_permlane32_swap): lanes 0..31 then hold rows 0, 1 of their even-step block in rB[0..3]
+        // and of the odd-step block in rB[4..7], lanes 32..63 rows 2, 3 of the same two blocks; likewise the record words
+#pragma unroll
+        for (int k = 0; k < 4; k++) wv::swap32(rB[k], rB[k + 4]);
+        dEven = dOdd = dC;
+        wv::swap32(dEven, dOdd);
         load_coefs_chroma(s + 2);
         kN1 = load_kind(s + 2);
       }
@@ -1159,14 +1173,16 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       wv::wave_sync();
       PH(2);  // chroma residuals, prefetch
 
-      // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (row gc, plane, block) ===================
+      // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (block half, row gc, plane, block) =======
       {
+        int kindC, qpP, cmode;
+        checked(evenStep ? dEven : dOdd, kindC, qpP, cmode);
         const int ringP = ts + S_RINGC + RINGC_ROW * gc + 8 * cpl;
         const int leftC = ts + S_LEFTC + 16 * gc + 8 * cpl;
         const unsigned tw = wv::lds_u32(ringP + RINGC_ENT * (xC & 3) + 4 * ccx);
         const unsigned lw = wv::lds_u32(leftC + 4 * ccy);
         unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
-        if (wv::any(chromaLane && cmode == 0)) {
+        if (wv::any(cmode == 0)) {
           const int st = (int)wv::sad4(tw), sl = (int)wv::sad4(lw);
           // trans_chroma.rs:168-286 incl. quirk Q2 (`> 0` where the spec means "available"):
           //   blocks (0,0),(4,4): both -> 8-sample mean; left only -> left; top only needs every top sample > 0
@@ -1191,13 +1207,15 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         } else {
           src = 0;  // plane: below
         }
-        unsigned p01[4], p23[4];
+        selA += inc * (unsigned)(2 * half);  // this lane's rows: 2 * half, 2 * half + 1
+        selB += inc * (unsigned)(2 * half);
+        unsigned p01[2], p23[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 2; k++) {
           p01[k] = wv::perm(src, src, selA + inc * k);
           p23[k] = wv::perm(src, src, selB + inc * k);
         }
-        if (wv::any(chromaLane && validC && kindC != 3 && cmode == 3)) {
+        if (wv::any(validC && kindC != 3 && cmode == 3)) {
           // plane (:319-363): H = sum (k+1)(T[4+k] - T[2-k]), V likewise on the left column; T[-1] = L[-1] = corner
           const int k = cblk;
           const int rT = ringP + RINGC_ENT * (xC & 3);
@@ -1213,13 +1231,13 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
             const int a = 16 * ((int)wv::lds_u8(leftC + 7) + (int)wv::lds_u8(rT + 7));
             const int bq = (34 * hs + 32) >> 6, c = (34 * vs + 32) >> 6;
             // pixel (x, y) of the plane: clip255((a + b (x-3) + c (y-3) + 16) >> 5); all terms fit 16 bits
-            const int base = a + bq * (4 * ccx - 3) + c * (4 * ccy - 3) + 16;
+            const int base = a + bq * (4 * ccx - 3) + c * (4 * ccy + 2 * half - 3) + 16;
             const unsigned b01 = ((unsigned)base & 0xffffu) | ((unsigned)(base + bq) << 16);
             const unsigned step2 = ((unsigned)(2 * bq) & 0xffffu) | ((unsigned)(2 * bq) << 16);
             const unsigned cc = ((unsigned)c & 0xffffu) | ((unsigned)c << 16);
             unsigned q01 = b01, q23 = wv::pk_add(b01, step2);
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
+            for (int kk = 0; kk < 2; kk++) {
               const unsigned u01 = wv::sat_pk_u8(wv::pk_ashr5(q01)), u23 = wv::sat_pk_u8(wv::pk_ashr5(q23));
               p01[kk] = wv::perm(0u, u01, 0x0c010c00u);
               p23[kk] = wv::perm(0u, u23, 0x0c010c00u);
@@ -1230,15 +1248,20 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         }
         if (wv::any(kindC == 3)) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < 2; k++) {
             p01[k] = kindC == 3 ? 0u : p01[k];
             p23[k] = kindC == 3 ? 0u : p23[k];
           }
         }
-        if (chromaLane) {
-          const int st = ts + S_STC + 16 * CW * gc + 8 * CW * cpl + CW * (4 * ccy) + 8 * slotC + 4 * ccx;
+        {
+          const int st = ts + S_STC + 16 * CW * gc + 8 * CW * cpl + CW * (4 * ccy + 2 * half) + 8 * slotC + 4 * ccx;
+          if (evenStep) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) wv::lds_st32(st + CW * k, recon_row(p01[k], p23[k], rB[2 * k], rB[2 * k + 1]));
+            for (int k = 0; k < 2; k++) wv::lds_st32(st + CW * k, recon_row(p01[k], p23[k], rB[2 * k], rB[2 * k + 1]));
+          } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) wv::lds_st32(st + CW * k, recon_row(p01[k], p23[k], rB[4 + 2 * k], rB[5 + 2 * k]));
+          }
         }
       }
 

@@ -37,17 +37,11 @@ WV int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL
 // move into the instruction that uses it
 template <int CTRL>
 WV int dppx(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xF, 0xF, true); }
-// Mode-grid neighbours (one 16-lane DPP row = a 4x4 grid, lane = 4 * row + column): min(x, m of the lane to the left
-// unless this lane is in column 0, m of the lane one grid row up unless this lane is in row 0). Two v_min_i32_dpp that
-// write only the lanes that have such a neighbour (row_shr:1 with bank 0 masked off; row_shr:4, whose first four lanes
-// have no source). Inline asm because the compiler turns the equivalent builtin form into two moves and a v_min3; the
-// s_nop covers the two wait states between a vector write of m and a DPP read of it, which it cannot see in here.
-WV int grid_min(int x, int m) {
-  asm("s_nop 1\n\tv_min_i32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xe\n\t"
-      "v_min_i32_dpp %0, %1, %0 row_shr:4 row_mask:0xf bank_mask:0xf"
-      : "+v"(x)
-      : "v"(m));
-  return x;
+// lanes 32..63 of a <-> lanes 0..31 of b (v_permlane32_swap_b32)
+WV void swap32(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
 }
 WV int bperm(int v, int srcLane) { return __builtin_amdgcn_ds_bpermute(srcLane << 2, v); }
 WV int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -206,15 +200,13 @@ WV int dpp(int old, int src) {
 }
 template <int CTRL>
 WV int dppx(int src) { return dpp<CTRL>(src, src); }
-WV int grid_min(int x, int m) {
-  const int l = lane_id(), i = l & 15;
-  g_emu.xbuf[l] = m;
-  emu_barrier("grid_min");
-  int r = x;
-  if ((i & 3) != 0) r = g_emu.xbuf[l - 1] < r ? g_emu.xbuf[l - 1] : r;
-  if (i >= 4) r = g_emu.xbuf[l - 4] < r ? g_emu.xbuf[l - 4] : r;
-  emu_barrier("grid_min2");
-  return r;
+WV void swap32(unsigned& a, unsigned& b) {
+  const int l = lane_id();
+  g_emu.xbuf[l] = (int)(l < 32 ? b : a);  // what this lane gives away
+  emu_barrier("swap32");
+  if (l < 32) b = (unsigned)g_emu.xbuf[l + 32];
+  else a = (unsigned)g_emu.xbuf[l - 32];
+  emu_barrier("swap32b");
 }
 WV int bperm(int v, int srcLane) {
   const int l = lane_id();
