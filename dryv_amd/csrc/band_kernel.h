@@ -1393,10 +1393,11 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     PH(0);  // wait for the record
 
     // (the bottom luma lines of the band above are in row 0's ring: FRONT fetched them)
-    // top border of the luma tile, first part: corner dword of x-1, 16 bytes of x
-    if (i < 5) {
-      const int e = i == 0 ? x - 1 : x;
-      const int so = i == 0 ? 12 : 4 * (i - 1);
+    // top border of the luma tile: corner dword of x-1, 16 bytes of x, 8 bytes of x+1 (the top-right neighbour: its
+    // row above finished it in the previous step, or FRONT fetched it with this step's record)
+    if (i < 7) {
+      const int e = i == 0 ? x - 1 : i < 5 ? x : x + 1;
+      const int so = i == 0 ? 12 : i < 5 ? 4 * (i - 1) : 4 * (i - 5);
       const unsigned v = wv::lds_u32(ringy(ts, g, e, par) + so);
       wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
     }
@@ -1481,12 +1482,6 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       wv::wave_sync();
       PH(2);  // Intra16x16
 
-      // ================= top-right neighbour: 8 bytes of x+1
-      if (i == 5 || i == 6) {
-        const unsigned v = wv::lds_u32(ringy(ts, g, x + 1, par) + 4 * (i - 5));
-        wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
-      }
-      wv::wave_sync();
       // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom line (and the
       // staged row segments). Once vmcnt says that everything this wave has issued is done the macroblock is published.
       if (linePend) {
