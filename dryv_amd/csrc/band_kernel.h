@@ -1527,12 +1527,9 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                    \
           const u32x2 enN = wv::lds_u64(entB + (int)mN);                                                          \
           const unsigned rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                          \
-          const int a0 = (int)wv::lds_u8(orgB + (int)((en.x >> 8) & 0xffu) + offT);                               \
-          const int a1 = (int)wv::lds_u8(orgB + (int)((en.x >> 16) & 0xffu) + offT);                              \
-          const int a2 = (int)wv::lds_u8(orgB + (int)(en.x >> 24) + offT);                                        \
-          const int b0 = (int)wv::lds_u8(orgB + (int)((en.y >> 8) & 0xffu) + offT);                               \
-          const int b1 = (int)wv::lds_u8(orgB + (int)((en.y >> 16) & 0xffu) + offT);                              \
-          const int b2 = wv::opaque((int)wv::lds_u8(orgB + (int)(en.y >> 24) + offT));                            \
+          const int a0 = (int)wv::lds_u8(q0 + offT), a1 = (int)wv::lds_u8(q1 + offT), a2 = (int)wv::lds_u8(q2 + offT); \
+          const int b0 = (int)wv::lds_u8(q3 + offT), b1 = (int)wv::lds_u8(q4 + offT);                             \
+          const int b2 = wv::opaque((int)wv::lds_u8(q5 + offT));                                                  \
           int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                       \
           int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                       \
           if (DC) {                                                                                               \
@@ -1559,6 +1556,11 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           constexpr int byN = stepByLo(TN), bxN = TN - 2 * byN;                                                   \
           constexpr int offT = TILE_STRIDE * 4 * by0 + 4 * bx0;                                                   \
           const bool act = mine && (two || ch == 0);                                                              \
+          /* sample addresses: base + table offset behind an optimisation barrier, so that the round's constant */ \
+          /* rides in the loads' immediate offset instead of being added to the base once per round */            \
+          const int q0 = wv::opaque(orgB + (int)((en.x >> 8) & 0xffu)), q1 = wv::opaque(orgB + (int)((en.x >> 16) & 0xffu)); \
+          const int q2 = wv::opaque(orgB + (int)(en.x >> 24)), q3 = wv::opaque(orgB + (int)((en.y >> 8) & 0xffu)); \
+          const int q4 = wv::opaque(orgB + (int)((en.y >> 16) & 0xffu)), q5 = wv::opaque(orgB + (int)(en.y >> 24)); \
           /* (wave-uniform: FRONT marked the rounds in which some block of the step is predicted DC) */           \
           if (dcRounds & (1u << (T))) I4_BODY(T, true) else I4_BODY(T, false)                                     \
           wv::wave_sync();                                                                                        \
