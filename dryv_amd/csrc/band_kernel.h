@@ -1541,6 +1541,9 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
             /* one sum alone counts twice: (sm + 2) >> 2 == (2 * sm + 4) >> 3 */                                  \
             int dc = ((sm << ((topAv && leftAv) ? 0 : 1)) + 4) >> 3;                                              \
             if (!topAv && !leftAv) dc = 128;                                                                      \
+            /* (opaque: otherwise the compiler, seeing that only 16 bits of dc are used, narrows the whole sum to */ \
+            /* 16-bit arithmetic and masks every loaded byte) */                                                  \
+            dc = wv::opaque(dc);                                                                                  \
             if (en.x & 32u) pa = pb = dc;                                                                         \
           }                                                                                                       \
           const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));              \
