@@ -1494,24 +1494,29 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       const bool anyI4 = wv::any(valid && kind == 0);
 
       // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================
-      // lane = (row g, block half ch, pixel pair cp): pixels (2*(cp&1) + {0,1}, cp>>1) of the step's block
+      // lane = (row g, block half ch, pixel pair cp). Rounds with two blocks per macroblock (2..7): pixels
+      // (2 * (cp & 1) + {0, 1}, cp >> 1) of block (bx0, by0) for ch = 0, of block (bx0 - 2, by0 + 1) for ch = 1. Rounds with
+      // one block (0, 1, 8, 9): all sixteen lanes work on it, one pixel each: (2 * (cp & 1) + ch, cp >> 1).
       if (anyI4) {
         const bool mine = valid && kind == 0;
         const int px = 2 * (cp & 1), py = cp >> 1;
         const int seqA = ts + S_MSEQ + 96 * buf + 24 * g + 12 * ch;
         // Everything a round addresses is a per-lane base (computed once per step) plus a constant of the round, which
         // the LDS instructions carry as their immediate offset: the second block of a two-block round is always
-        // (bx - 2, by + 1) of the first, so its lanes' bases differ from the first block's by a constant (in the rounds
-        // with one block those lanes compute on whatever is there and store nothing).
-        const int orgB = tile + 8 + 16 * slot - 1 + (ch ? 4 * TILE_STRIDE - 8 : 0);  // (block origin - one row - one column) of block (0, 0) / (-2, 1)
-        const int stB = orgB + TILE_STRIDE * (py + 1) + 1 + px;
-        const int resB = resBuf + 512 * g + 4 * cp + (ch ? 64 : 0);   // residuals: [4 * by + bx]
-        const int entB = ldsBase + T_T4E + 96 * cp;
-        const bool chOrB = ch != 0 || mbB, nchOrA = ch == 0 || mbA;
-        // the table rows of all ten steps (they do not depend on pixels), then entry and residual one step ahead
+        // (bx - 2, by + 1) of the first, so its lanes' bases differ from the first block's by a constant.
+        const int orgS = tile + 8 + 16 * slot - 1;                  // (block origin - one row - one column) of block (0, 0)
+        const int orgB = orgS + (ch ? 4 * TILE_STRIDE - 8 : 0);     // ... of block (0, 0) / (-2, 1)
+        const int stB = orgB + TILE_STRIDE * (py + 1) + 1 + px, stS = orgS + TILE_STRIDE * (py + 1) + 1 + px + ch;
+        const int resS = resBuf + 512 * g + 4 * cp + 2 * ch;        // residuals [4 * by + bx][y][x]: this lane's one pixel
+        const int resB = resBuf + 512 * g + 4 * cp + (ch ? 64 : 0); // ... this lane's pixel pair
+        const int entB = ldsBase + T_T4E + 96 * cp, entS = entB + 4 * ch;
+        const bool nchOrA = ch == 0 || mbA;
+        // the table rows of all ten steps (they do not depend on pixels): this lane's block half, and the first half's
+        // for the one-block rounds; then entry and residual one step ahead
         const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
-        u32x2 en = wv::lds_u64(entB + (int)(sq0 & 0xffu));
-        unsigned rr = wv::lds_u32(resB);
+        const unsigned sS0 = wv::lds_u32(seqA - 12 * ch), sS2 = wv::lds_u32(seqA - 12 * ch + 8);
+        u32x2 en = u32x2{wv::lds_u32(entS + (int)(sS0 & 0xffu)), 0u};
+        unsigned rr = (unsigned)wv::lds_i16(resS);
         const unsigned dcRounds = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 28));
 #define I4_BODY(T, DC)                                                                                           \
         {                                                                                                         \
@@ -1520,34 +1525,58 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           unsigned top = 0;                                                                                       \
           int l0 = 0, l1 = 0, l2 = 0, l3 = 0;                                                                     \
           if (DC) {                                                                                               \
-            top = wv::lds_u32(orgB + offT + 1);                                                                   \
-            l0 = (int)wv::lds_u8(orgB + offT + TILE_STRIDE), l1 = (int)wv::lds_u8(orgB + offT + 2 * TILE_STRIDE); \
-            l2 = (int)wv::lds_u8(orgB + offT + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(orgB + offT + 4 * TILE_STRIDE); \
+            const int orgX = two ? orgB : orgS;                                                                   \
+            top = wv::lds_u32(orgX + offT + 1);                                                                   \
+            l0 = (int)wv::lds_u8(orgX + offT + TILE_STRIDE), l1 = (int)wv::lds_u8(orgX + offT + 2 * TILE_STRIDE); \
+            l2 = (int)wv::lds_u8(orgX + offT + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(orgX + offT + 4 * TILE_STRIDE); \
           }                                                                                                       \
-          const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                    \
-          const u32x2 enN = wv::lds_u64(entB + (int)mN);                                                          \
-          const unsigned rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                          \
-          const int a0 = (int)wv::lds_u8(q0 + offT), a1 = (int)wv::lds_u8(q1 + offT), a2 = (int)wv::lds_u8(q2 + offT); \
-          const int b0 = (int)wv::lds_u8(q3 + offT), b1 = (int)wv::lds_u8(q4 + offT);                             \
-          const int b2 = wv::opaque((int)wv::lds_u8(q5 + offT));                                                  \
-          int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                       \
-          int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                       \
-          if (DC) {                                                                                               \
-            /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch). */ \
-            /* Availability of the round's blocks: (bx0, by0) for ch = 0, (bx0 - 2, by0 + 1) for ch = 1 */        \
-            const bool topAv = by0 > 0 ? true : chOrB;                                                            \
-            const bool leftAv = two ? (bx0 == 2 ? nchOrA : true) : (bx0 > 0 ? true : mbA);                        \
-            const int sm = (topAv ? (int)wv::sad4(top) : 0) + (leftAv ? l0 + l1 + l2 + l3 : 0);                   \
-            /* one sum alone counts twice: (sm + 2) >> 2 == (2 * sm + 4) >> 3 */                                  \
-            int dc = ((sm << ((topAv && leftAv) ? 0 : 1)) + 4) >> 3;                                              \
-            if (!topAv && !leftAv) dc = 128;                                                                      \
-            /* (opaque: otherwise the compiler, seeing that only 16 bits of dc are used, narrows the whole sum to */ \
-            /* 16-bit arithmetic and masks every loaded byte) */                                                  \
-            dc = wv::opaque(dc);                                                                                  \
-            if (en.x & 32u) pa = pb = dc;                                                                         \
+          u32x2 enN = en;                                                                                         \
+          unsigned rrN;                                                                                           \
+          if (twoN) {                                                                                             \
+            const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                  \
+            enN = wv::lds_u64(entB + (int)mN);                                                                    \
+            rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                                       \
+          } else {                                                                                                \
+            const unsigned mN = ((TN < 4 ? sS0 : sS2) >> (8 * (TN & 3))) & 0xffu;                                 \
+            enN.x = wv::lds_u32(entS + (int)mN);                                                                  \
+            rrN = (unsigned)wv::lds_i16(resS + 32 * (4 * byN + bxN));                                             \
           }                                                                                                       \
-          const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));              \
-          if (act) wv::lds_st16(stB + offT, o);                                                                   \
+          if (two) {                                                                                              \
+            const int a0 = (int)wv::lds_u8(q0 + offT), a1 = (int)wv::lds_u8(q1 + offT), a2 = (int)wv::lds_u8(q2 + offT); \
+            const int b0 = (int)wv::lds_u8(q3 + offT), b1 = (int)wv::lds_u8(q4 + offT);                           \
+            const int b2 = wv::opaque((int)wv::lds_u8(q5 + offT));                                                \
+            int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                     \
+            int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                     \
+            if (DC) {                                                                                             \
+              /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch). */ \
+              /* Availability of the round's blocks: (bx0, by0) for ch = 0, (bx0 - 2, by0 + 1) for ch = 1 */      \
+              const bool topAv = by0 > 0 ? true : (ch != 0 || mbB);                                               \
+              const bool leftAv = bx0 == 2 ? nchOrA : true;                                                       \
+              const int sm = (topAv ? (int)wv::sad4(top) : 0) + (leftAv ? l0 + l1 + l2 + l3 : 0);                 \
+              /* one sum alone counts twice: (sm + 2) >> 2 == (2 * sm + 4) >> 3 */                                \
+              int dc = ((sm << ((topAv && leftAv) ? 0 : 1)) + 4) >> 3;                                            \
+              if (!topAv && !leftAv) dc = 128;                                                                    \
+              /* (opaque: otherwise the compiler, seeing that only 16 bits of dc are used, narrows the whole sum */ \
+              /* to 16-bit arithmetic and masks every loaded byte) */                                             \
+              dc = wv::opaque(dc);                                                                                \
+              if (en.x & 32u) pa = pb = dc;                                                                       \
+            }                                                                                                     \
+            const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));            \
+            if (mine) wv::lds_st16(stB + offT, o);                                                                \
+          } else {                                                                                                \
+            const int a0 = (int)wv::lds_u8(q0 + offT), a1 = (int)wv::lds_u8(q1 + offT);                           \
+            const int a2 = wv::opaque((int)wv::lds_u8(q2 + offT));                                                \
+            int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                     \
+            if (DC) {                                                                                             \
+              const bool topAv = by0 > 0 ? true : mbB, leftAv = bx0 > 0 ? true : mbA;                             \
+              const int sm = (topAv ? (int)wv::sad4(top) : 0) + (leftAv ? l0 + l1 + l2 + l3 : 0);                 \
+              int dc = ((sm << ((topAv && leftAv) ? 0 : 1)) + 4) >> 3;                                            \
+              if (!topAv && !leftAv) dc = 128;                                                                    \
+              if (en.x & 32u) pa = dc;                                                                            \
+            }                                                                                                     \
+            const int o = wv::med3(pa + (int)rr, 0, 255);                                                         \
+            if (mine) wv::lds_st8(stS + offT, (unsigned)o);                                                       \
+          }                                                                                                       \
           en = enN;                                                                                               \
           rr = rrN;                                                                                               \
         }
@@ -1557,13 +1586,18 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           constexpr bool two = by0 + 1 <= stepByHi(T);                                                            \
           constexpr int TN = (T) < 9 ? (T) + 1 : 9;                                                               \
           constexpr int byN = stepByLo(TN), bxN = TN - 2 * byN;                                                   \
+          constexpr bool twoN = byN + 1 <= stepByHi(TN);                                                          \
           constexpr int offT = TILE_STRIDE * 4 * by0 + 4 * bx0;                                                   \
-          const bool act = mine && (two || ch == 0);                                                              \
           /* sample addresses: base + table offset behind an optimisation barrier, so that the round's constant */ \
           /* rides in the loads' immediate offset instead of being added to the base once per round */            \
-          const int q0 = wv::opaque(orgB + (int)((en.x >> 8) & 0xffu)), q1 = wv::opaque(orgB + (int)((en.x >> 16) & 0xffu)); \
-          const int q2 = wv::opaque(orgB + (int)(en.x >> 24)), q3 = wv::opaque(orgB + (int)((en.y >> 8) & 0xffu)); \
-          const int q4 = wv::opaque(orgB + (int)((en.y >> 16) & 0xffu)), q5 = wv::opaque(orgB + (int)(en.y >> 24)); \
+          const int orgQ = two ? orgB : orgS;                                                                     \
+          const int q0 = wv::opaque(orgQ + (int)((en.x >> 8) & 0xffu)), q1 = wv::opaque(orgQ + (int)((en.x >> 16) & 0xffu)); \
+          const int q2 = wv::opaque(orgQ + (int)(en.x >> 24));                                                    \
+          int q3 = 0, q4 = 0, q5 = 0;                                                                             \
+          if (two) {                                                                                              \
+            q3 = wv::opaque(orgB + (int)((en.y >> 8) & 0xffu)), q4 = wv::opaque(orgB + (int)((en.y >> 16) & 0xffu)); \
+            q5 = wv::opaque(orgB + (int)(en.y >> 24));                                                            \
+          }                                                                                                       \
           /* (wave-uniform: FRONT marked the rounds in which some block of the step is predicted DC) */           \
           if (dcRounds & (1u << (T))) I4_BODY(T, true) else I4_BODY(T, false)                                     \
           wv::wave_sync();                                                                                        \
