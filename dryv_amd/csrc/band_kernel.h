@@ -633,7 +633,7 @@ WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned known
                           unsigned task, int s, int lane) {
   unsigned spins = 0;
   while (known < need) {
-    const unsigned v = wv::ld_sc1(lane < 32 ? pa : pb);  // (all lanes: see the claim in band_front)
+    const unsigned v = wv::ld_sc1((const unsigned*)((const uint8_t*)pa + (lane < 32 ? 0u : 4u * (unsigned)(pb - pa))));  // (all lanes: see the claim in band_front)
     known = min((unsigned)wv::rfl((int)v), (unsigned)wv::rdlane((int)v, 32));
     if (known < need) {
       wv::sleep_short();
@@ -708,6 +708,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     unsigned* const myProg = A.progM + (size_t)G.f * nBands + G.b;
     const unsigned* const upProgM = myProg - 1;
     const unsigned* const upProgY = A.progY + (size_t)G.f * nBands + G.b - 1;
+    const unsigned progYtoM = 4u * (unsigned)(A.progM - A.progY);  // in bytes (both in the workspace: one base and a lane offset for the pollers)
 
     // ---- software pipeline: a step's record is fetched one step ahead (its first word, which decides the
     // coefficient layout, two steps ahead); its coefficients are fetched right after the previous step's residual
@@ -846,9 +847,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
       const bool fetchLane = needUp && li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+      // (two loads off wave-uniform bases, each under its lanes' mask, rather than one load off a per-lane choice of
+      // pointer: that would be 64-bit vector arithmetic)
       auto fetch_up = [&](int mb) -> unsigned {
-        if (li < 4) return wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mb + 4 * li)));
-        return wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mb)));
+        unsigned v = 0;
+        if (li < 4) v = wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mb + 4 * li)));
+        if (li == 4) v = wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mb)));
+        return v;
       };
       bool haveNext = false;
       if (needUp) {
@@ -865,7 +870,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         haveNext = s + 2 < W && upKnown >= (unsigned)(s + 3);
         if (haveNext && lane < 16 && li < 5) lineN = fetch_up(s + 2);
         if (upKnown < (unsigned)W) {
-          flagV = wv::ld_sc1(lane < 32 ? upProgY : upProgM);
+          flagV = wv::ld_sc1((const unsigned*)((const uint8_t*)upProgY + (lane < 32 ? 0u : progYtoM)));
           flagPend = true;
         }
       }
