@@ -1021,6 +1021,21 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
   const int pitchC = W * 8;
   const size_t frameBytes = (size_t)W * H * 384;
   const unsigned offCb = (unsigned)W * H * 256u, offCr = offCb + (unsigned)W * H * 64u;
+  // Write-out addresses: their lane-dependent parts never change, so they are computed once per kernel and kept (behind an
+  // optimisation barrier: the compiler would otherwise rebuild them from the lane id in every step).
+  const int hg = lane0 >> 4, hi = lane0 & 15;
+  const int aBot = wv::opaque(ts + S_STC + 16 * CW * hg + 8 * CW * (hi >> 1) + CW * 7 + 4 * (hi & 1));  // + 8 * slot: bottom line of a plane, lanes 0..3
+  const int aRing = wv::opaque(ts + S_RINGC + RINGC_ROW * (hg + 1) + 4 * hi);                          // + RINGC_ENT * (x & 3)
+  const int aLeftRd = wv::opaque(ts + S_STC + 16 * CW * hg + 8 * CW * (hi >> 3) + CW * (hi & 7) + 7);  // + 8 * slot: column 7
+  const int aLeftWr = wv::opaque(ts + S_LEFTC + 16 * hg + 8 * (hi >> 3) + (hi & 7));
+  // write-through of the band's bottom lines: + 8 * r0 * pitchC + 8 * s   (8 * x = 8 * s - 16 * g)
+  const unsigned oBot = (unsigned)wv::opaque((int)((hi < 2 ? offCb : offCr) + (unsigned)((8 * hg + 7) * pitchC - 16 * hg + 4 * (hi & 1))));
+  // flush with 64 lanes per macroblock row (NSC = 8): lane = (plane, pixel row, 16-byte segment)
+  constexpr int FLR = 8 * NSC;
+  const int fw = lane0 % FLR, fpl = fw / (FLR / 2), ffy = (fw / (NSC / 2)) & 7, fseg = fw % (NSC / 2);
+  const int aFlush = wv::opaque(ts + S_STC + 8 * CW * fpl + CW * ffy + 16 * fseg);                      // + 16 * CW * row
+  const unsigned oFlush = (unsigned)wv::opaque((int)((fpl ? offCr : offCb) + (unsigned)(ffy * pitchC + 16 * fseg)));  // + 8 * (r0 + row) * pitchC + 8 * xp
+  const int fseg2 = wv::opaque(2 * fseg + (ffy == 7 ? 64 : 0));   // 2 * segment; bit 6: pixel row 7
 
   for (unsigned seq = 0;; seq++) {
     team_wait_ge(ts + S_FLAGS + F_HEAD, seq + 1);
@@ -1285,21 +1300,17 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       // bottom chroma lines for the row below (ring) or the band below (write-through): lanes 0..1 of row g Cb, 2..3 Cr
       {
         unsigned v = 0;
-        if (i < 4) v = wv::lds_u32(ts + S_STC + 16 * CW * g + 8 * CW * (i >> 1) + CW * 7 + 8 * slot + 4 * (i & 1));
-        if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ts + S_RINGC + RINGC_ROW * (g + 1) + RINGC_ENT * (x & 3) + 4 * i, v);
+        if (i < 4) v = wv::lds_u32(aBot + 8 * slot);
+        if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(aRing + RINGC_ENT * (x & 3), v);
         if (hasBelow && wv::any(valid && g == gl)) {  // the band's last row: written through for the band below
-          if (valid && g == gl && i < 4) {
-            const unsigned off = (i < 2 ? offCb : offCr) + (unsigned)((8 * r + 7) * pitchC + 8 * x + 4 * (i & 1));
-            wv::st_sc1((unsigned*)(planeY + off), v);
-          }
+          if (valid && g == gl && i < 4) wv::st_sc1((unsigned*)(planeY + (oBot + (unsigned)(8 * r0 * pitchC + 8 * s))), v);
           linePend = true;
         }
       }
       // left neighbour copy: chroma column 7
       {
-        const int pl = i >> 3, yy = i & 7;
-        const unsigned c = wv::lds_u8(ts + S_STC + 16 * CW * g + 8 * CW * pl + CW * yy + 8 * slot + 7);
-        wv::lds_st8(ts + S_LEFTC + 16 * g + 8 * pl + yy, c);
+        const unsigned c = wv::lds_u8(aLeftRd + 8 * slot);
+        wv::lds_st8(aLeftWr, c);
       }
       wv::wave_sync();
       // flush the staged rows: every NSC-th macroblock, or at the end of a row: 8 * NSC contiguous bytes per pixel row.
@@ -1315,6 +1326,18 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
           const int fx = s - 2 * fg, xp = fx & ~(NSC - 1);
           const bool rowFlush = fg < nR && fx >= 0 && fx < W && ((fx & (NSC - 1)) == NSC - 1 || fx == W - 1);
           if (LR >= 64 && !rowFlush) continue;
+          if (LR == 64) {
+            // (everything lane-dependent was prepared before the task loop; the row's part is wave-uniform)
+            const int room = fx - xp;   // macroblocks of the segment in front of fx
+            const bool ok = (fseg2 & 63) <= room && !(hasBelow && fg == gl && (fseg2 & 64));
+            const u32x4 v = wv::lds_u128(aFlush + 16 * CW * fg);
+            uint8_t* dst = planeY + (oFlush + (unsigned)(8 * (r0 + fg) * pitchC + 8 * xp));
+            if (ok) {
+              if ((fseg2 & 63) + 1 <= room) wv::st_g128(dst, v);
+              else wv::st_g64(dst, u32x2{v.x, v.y});
+            }
+            continue;
+          }
           const int pl = w / (LR / 2), fy = (w / (NSC / 2)) & 7, seg = w % (NSC / 2);
           const bool ok = rowFlush && xp + 2 * seg <= fx && !(hasBelow && fg == gl && fy == 7);
           const u32x4 v = wv::lds_u128(ts + S_STC + 16 * CW * fg + 8 * CW * pl + CW * fy + 16 * seg);
