@@ -1404,7 +1404,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     const bool hasBelow = G.hasBelow;
     const int resBuf = ts + S_RES + 2048 * buf;
 
-    const int lane = wv::opaque(lane0);
+    const int lane = lane0;  // (BACK has registers to spare: whatever depends on the lane alone is computed once, outside the loop)
     const int g = lane >> 4, i = lane & 15;
     const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
     const int ch = (i >> 3) & 1, cp = i & 7;                                          // Intra4x4 chain: block half, pixel pair
@@ -1464,7 +1464,12 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           p23[k] = wv::perm(src, src, selB + inc * k);
         }
         if (wv::any(valid && kind == 2 && i16mode == 3)) {
-          // plane (:366-424): lanes 0..7 of the row group: horizontal terms, 8..15: vertical terms
+          // plane (:366-424): lanes 0..7 of the row group: horizontal terms, 8..15: vertical terms.
+          // (its lane roles from an opaque lane id: they are then computed here, in the steps that have a plane macroblock,
+          // instead of living in registers for the whole kernel)
+          const int lane = wv::opaque(lane0);
+          const int g = lane >> 4, i = lane & 15;
+          const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);
           const int k = i & 7;
           const int tr0 = tile + 8 + 16 * slot, lf = ts + S_LEFTY + 16 * g;
           const int corner = (int)wv::lds_u8(tr0 - 1);
