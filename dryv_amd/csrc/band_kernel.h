@@ -670,6 +670,14 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
   const int pitchY = W * 16;
   const size_t frameBytes = (size_t)W * H * 384;
   unsigned gstep = 0;  // steps of this team so far, over all its tasks: buffer = parity, flags carry gstep + 1
+  // FRONT is the wave at the register limit: its lane roles are recomputed in every step, except these four, which save
+  // the most arithmetic per register (kept behind an optimisation barrier)
+  const int hi4 = lane0 & 15, hzbx = ((hi4 >> 1) & 2) | (hi4 & 1), hzby = ((hi4 >> 2) & 2) | ((hi4 >> 1) & 1);
+  const int hPermDc = wv::opaque((lane0 & 48) + zidx((0x1320 >> (4 * hzbx)) & 3, (0x1320 >> (4 * hzby)) & 3));  // Intra16x16 DC: source lane of the last stage
+  const int hResOff = wv::opaque(512 * (lane0 >> 4) + 32 * (4 * hzby + hzbx));                                   // this lane's block in the residual record
+  const int hMzb4 = wv::opaque(4 * zidx(hi4 & 3, hi4 >> 2));                                                     // 4 x blkIdx of its mode-grid position
+  const int ht4 = (hi4 & 3) + 2 * (hi4 >> 2);
+  const int hSeqOff = wv::opaque(24 * (lane0 >> 4) + 12 * ((hi4 >> 2) != stepByLo(ht4) ? 1 : 0) + ht4);          // its byte of the chain's table-row sequence
 
   for (unsigned seq = 0;; seq++) {
     // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
@@ -806,8 +814,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           v = (zby & 1) ? o - v : v + o;
           o = xor8(v);
           v = (zby & 2) ? o - v : v + o;
-          const int sxx = (0x1320 >> (4 * zbx)) & 3, syy = (0x1320 >> (4 * zby)) & 3;
-          const int fv = wv::bperm(v, (lane & 48) + zidx(sxx, syy));
+          const int fv = wv::bperm(v, hPermDc);  // lane (s(bx), s(by)) of the row group, s = [0, 2, 3, 1]
           // qp >= 36: (f*LS) << (qp/6-6), else (f*LS + 2^(5-qp/6)) >> (6-qp/6)   (pred16x16.rs:465-479)
           const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
           const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
@@ -894,7 +901,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           wv::lds_st16(dst + 256 * p + 128 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
         }
       } else {
-        const int dst = ts + S_RES + 2048 * buf + 512 * g + 32 * (4 * zby + zbx);
+        const int dst = ts + S_RES + 2048 * buf + hResOff;
         wv::lds_st128(dst, u32x4{rA[0], rA[1], rA[2], rA[3]});
         wv::lds_st128(dst + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
       }
@@ -923,7 +930,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       const bool anyI4 = wv::any(valid && (kind == 0 || (HAS_I8 && kind == 1)));
       if (anyI4) {
         const bool is8 = HAS_I8 && kind == 1;
-        const int mzb = is8 ? 2 * (rby >> 1) + (rbx >> 1) : zidx(rbx, rby);
+        const int mzb = is8 ? 2 * (rby >> 1) + (rbx >> 1) : hMzb4 >> 2;
         const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
         const bool prev = ((prevFlags >> mzb) & 1u) != 0;
         const unsigned upM = mbB ? wv::lds_u32(ts + S_RINGM + 16 * g + 4 * (x & 3)) : 0x02020202u;
@@ -958,8 +965,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         if (kind == 0) {
           Mcur = M;
           const int t = rbx + 2 * rby;
-          const int hh = rby != stepByLo(t) ? 1 : 0;
-          wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + 12 * hh + t, (unsigned)(8 * Mp));  // (the table row's offset)
+          wv::lds_st8(ts + S_MSEQ + 96 * buf + hSeqOff, (unsigned)(8 * Mp));  // (the table row's offset)
           // BACK skips the DC arithmetic (and its samples) in the rounds where no block of the step is predicted DC
           if (valid && Mp == 2) wv::lds_or32(ts + S_INFO + 32 * buf + 28, 1u << t);
         } else if (is8) {
