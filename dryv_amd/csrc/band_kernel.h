@@ -1100,7 +1100,13 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
 
     for (int s = 0; s < nSteps; s++) {
       const bool evenStep = (s & 1) == 0;
-      if (evenStep) dC = kN1;
+      if (evenStep) {
+        // the record checks FRONT makes (it also reports them), once per pair of steps: an unsupported record becomes
+        // kind 3 / qp 0 here, reconstructs as zero, and is only read field by field afterwards
+        dC = kN1;
+        const unsigned kd = dC & 0xffu;
+        if (kd > 2u || (!HAS_I8 && kd == 1u) || (dC >> 24) > 51u || ((dC >> 8) & 0xffu) > 3u || ((dC >> 16) & 0xffu) > 3u) dC = 3u;
+      }
       const int lane = wv::opaque(lane0);
       const int g = lane >> 4, i = lane & 15;                                            // write-out organisation: row g
       // residuals: lane = (half of the pair of steps, row gc, plane, block): lanes 32..63 work on the odd step's blocks.
@@ -1116,19 +1122,8 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       const int slot = x & (NSC - 1), slotC = xC & (NSC - 1);  // staging columns
       const bool needUp = hasAbove && s < W;
       unsigned lineV = 0;
-      // the record checks FRONT makes (it also reports them): an unsupported record reconstructs as zero.
-      // dC: the residual lane's macroblock (of its step of the pair); dP: the prediction lane's (of this step)
-      auto checked = [&](unsigned d, int& kind, int& qp, int& mode) {
-        kind = (int)(d & 0xffu);
-        qp = (int)(d >> 24);
-        mode = (int)((d >> 16) & 0xffu);
-        if (kind > 2 || (!HAS_I8 && kind == 1) || qp > 51 || ((d >> 8) & 0xffu) > 3u || mode > 3) {
-          kind = 3;
-          qp = 0;
-        }
-      };
-      int kindR, qpR, cmodeR;
-      checked(dC, kindR, qpR, cmodeR);
+      // dC: the residual lane's macroblock (of its step of the pair); dEven / dOdd: the prediction lane's (of this step)
+      const int kindR = (int)(dC & 0xffu), qpR = (int)(dC >> 24);
 
       // ---- hand-off traffic. Publish: the previous step ended with the write-through stores of its last-row
       // macroblock's bottom chroma lines (and the staged row segments); once vmcnt says that everything this wave has
@@ -1201,8 +1196,8 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
 
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (block half, row gc, plane, block) =======
       {
-        int kindC, qpP, cmode;
-        checked(evenStep ? dEven : dOdd, kindC, qpP, cmode);
+        const unsigned dP = evenStep ? dEven : dOdd;
+        const int kindC = (int)(dP & 0xffu), cmode = (int)((dP >> 16) & 0xffu);
         const int ringP = ts + S_RINGC + RINGC_ROW * gc + 8 * cpl;
         const int leftC = ts + S_LEFTC + 16 * gc + 8 * cpl;
         const unsigned tw = wv::lds_u32(ringP + RINGC_ENT * (xC & 3) + 4 * ccx);
