@@ -1042,6 +1042,8 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
   const int aFlush = wv::opaque(ts + S_STC + 8 * CW * fpl + CW * ffy + 16 * fseg);                      // + 16 * CW * row
   const unsigned oFlush = (unsigned)wv::opaque((int)((fpl ? offCr : offCb) + (unsigned)(ffy * pitchC + 16 * fseg)));  // + 8 * (r0 + row) * pitchC + 8 * xp
   const int fseg2 = wv::opaque(2 * fseg + (ffy == 7 ? 64 : 0));   // 2 * segment; bit 6: pixel row 7
+  // the band above's bottom lines (lanes 0..1 of a row group Cb, 2..3 Cr): + (8 * r0 - 1) * pitchC + 8 * macroblock
+  const unsigned oUp = (unsigned)wv::opaque((int)(((hi & 15) < 2 ? offCb : offCr) + (unsigned)(4 * (hi & 1))));
 
   for (unsigned seq = 0;; seq++) {
     team_wait_ge(ts + S_FLAGS + F_HEAD, seq + 1);
@@ -1143,8 +1145,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       const int mbx = lane < 16 ? s + 1 : 0;
       const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
       auto fetch_up = [&](int mb) -> unsigned {
-        const unsigned off = (li < 2 ? offCb : offCr) + (unsigned)((8 * r0 - 1) * pitchC + 8 * mb + 4 * (li & 1));
-        return wv::ld_sc1((const unsigned*)(planeY + off));
+        return wv::ld_sc1((const unsigned*)(planeY + (oUp + (unsigned)((8 * r0 - 1) * pitchC + 8 * mb))));
       };
       bool haveNext = false;
       if (needUp) {
