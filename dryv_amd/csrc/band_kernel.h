@@ -349,15 +349,17 @@ WV void idct4x4_wide(const u32x4 c0, const u32x4 c1, int lsAddr, int shl, int rn
 // whose 64 blocks all pass (block_fits16) takes this path; one block that does not sends the wave through idct4x4<int>.
 // sum of |c| over the block's 16 entries (entry 0 excluded when it is not a coefficient of this block)
 WV unsigned sum_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
-  const unsigned b = 0x80008000u;  // c ^ 0x8000 = c + 32768 as an unsigned half: |that - 32768| = |c|
-  unsigned a = wv::sad_u16((skip0 ? c0.x & 0xffff0000u : c0.x) ^ b, b, 0u);
-  a = wv::sad_u16(c0.y ^ b, b, a);
-  a = wv::sad_u16(c0.z ^ b, b, a);
-  a = wv::sad_u16(c0.w ^ b, b, a);
-  a = wv::sad_u16(c1.x ^ b, b, a);
-  a = wv::sad_u16(c1.y ^ b, b, a);
-  a = wv::sad_u16(c1.z ^ b, b, a);
-  return wv::sad_u16(c1.w ^ b, b, a);
+  // On unsigned halves |c - 0x8000| = 32768 - |c| for either sign of the int16 c (c >= 0: 32768 - c; c < 0: its bits are
+  // 65536 + c, so 32768 + c), hence eight v_sad_u16 against 0x8000 give 16 * 32768 - sum |c| without touching the inputs
+  const unsigned b = 0x80008000u;
+  unsigned a = wv::sad_u16(skip0 ? c0.x & 0xffff0000u : c0.x, b, 0u);
+  a = wv::sad_u16(c0.y, b, a);
+  a = wv::sad_u16(c0.z, b, a);
+  a = wv::sad_u16(c0.w, b, a);
+  a = wv::sad_u16(c1.x, b, a);
+  a = wv::sad_u16(c1.y, b, a);
+  a = wv::sad_u16(c1.z, b, a);
+  return 16u * 32768u - wv::sad_u16(c1.w, b, a);
 }
 WV bool block_fits16(const u32x4 c0, const u32x4 c1, int ldsBase, int qp, bool useDc, long long dcVal) {
   const unsigned sa = min(sum_abs16(c0, c1, useDc), 32768u);            // (<= 2^15: the product below fits 32 bits)
