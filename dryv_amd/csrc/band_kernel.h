@@ -1,4 +1,4 @@
-// band_kernel.h — macroblock reconstruction, one TEAM of two wavefronts per band of four macroblock rows (gfx950).
+// band_kernel.h — macroblock reconstruction, one TEAM of three wavefronts per band of four macroblock rows (gfx950).
 //
 // Decomposition
 //   * The unit of work is a band: 4 consecutive macroblock rows of one frame. Lanes 16g..16g+15 of a wave belong to
@@ -29,16 +29,21 @@
 //   * residual: ONE LANE PER 4x4 BLOCK. The lane loads its block's 16 coefficients (32 contiguous bytes of the
 //     reference's list order) straight into registers, so the inverse zig-zag is register renaming, both butterfly
 //     passes are in-lane, and no transpose exists. Luma: 64 lanes = 4 MB x 16 blocks; chroma: 32 lanes = 4 MB x
-//     2 planes x 4 blocks. Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP.
+//     2 planes x 4 blocks, so CHROMA computes two steps' residuals per pass and then hands the halves over
+//     (v_permlane32_swap): every step's chroma prediction runs on all 64 lanes, half a block per lane.
+//     Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP.
 //     int32 arithmetic with a per-qp coefficient bound (KParams::thr4). A block beyond it flags the batch, and the
 //     host re-runs the batch with the WIDE build of this kernel, whose passes switch to int64 (reference: isize)
 //     for such waves: the result is the reference's for every int16 input.
 //   * Intra16x16 and chroma prediction use the same lane-per-block layout: V, H and DC are one v_perm_b32
 //     byte-select per pixel pair, plane is packed 16-bit arithmetic.
 //   * Intra4x4: prediction modes by the 7-sweep DPP relaxation over the block grid (one DPP row per macroblock),
-//     pixels by a 10-step 2:1 block wavefront with 8 lanes per block (2 pixels each): every pixel is
-//     (E[p] + 2E[q] + E[r] + 2) >> 2 of three samples whose tile offsets come from a per-(mode, pixel) table.
-//   * pixels are staged in LDS two macroblocks wide and stored as whole 32-byte row segments every other step.
+//     pixels by a 10-step 2:1 block wavefront with 8 lanes per block (2 pixels each; 16 lanes and one pixel each
+//     in the four rounds that have one block per macroblock): every pixel is (E[p] + 2E[q] + E[r] + 2) >> 2 of
+//     three samples whose tile offsets come from a per-(mode, pixel) table.
+//   * pixels are staged in LDS and stored as whole 64-byte row segments (NSY / NSC macroblocks at a time).
+//   * Whatever depends on the lane id alone is computed once per kernel where the registers allow (all of BACK; chosen
+//     constants in FRONT and CHROMA, which sit at the 80-register limit of six waves per SIMD).
 //
 // Written against wave.h: the same source runs on the GPU and, lane by lane, in the CPU emulator of tests/emu.
 #pragma once

@@ -7,7 +7,7 @@
 namespace dryv {
 
 // A workgroup = TEAMS_PER_WG teams of a FRONT, a BACK and a CHROMA wave. The fast build for streams without the 8x8
-// transform needs 68 VGPRs; the one with it is compiled for 5 waves per SIMD (96 VGPRs), the wide builds (64-bit residual
+// transform uses all 80 VGPRs that six waves per SIMD allow (lane-constant work hoisted up to that limit); the one with it is compiled for 5 waves per SIMD (96 VGPRs), the wide builds (64-bit residual
 // arithmetic, re-run of a flagged batch only) for 4.
 // Grid shape: tools/band_variants.sh (measurements in DESIGN.md).
 #ifndef DRYV_BAND_WPS
