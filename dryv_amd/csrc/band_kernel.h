@@ -783,7 +783,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       const bool rowOk = g < nR;
       const bool mbB = r > 0;
       const int x = s - 2 * g;
-      const bool valid = rowOk && x >= 0 && x < W;
+      const bool valid = rowOk && (unsigned)x < (unsigned)W;
       const bool needUp = hasAbove && s < W;
       unsigned lineV = 0;
 
@@ -1129,7 +1129,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       const int r = r0 + g, rC = r0 + gc;
       const bool mbBC = rC > 0;
       const int x = s - 2 * g, xC = s - 2 * gc;
-      const bool valid = g < nR && x >= 0 && x < W, validC = gc < nR && xC >= 0 && xC < W;
+      const bool valid = g < nR && (unsigned)x < (unsigned)W, validC = gc < nR && (unsigned)xC < (unsigned)W;
       const bool mbAC = xC > 0;
       const int slot = x & (NSC - 1), slotC = xC & (NSC - 1);  // staging columns
       const bool needUp = hasAbove && s < W;
@@ -1424,7 +1424,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     const bool rowOk = g < nR;
     const bool mbB = r > 0;
     const int x = s - 2 * g;
-    const bool valid = rowOk && x >= 0 && x < W;
+    const bool valid = rowOk && (unsigned)x < (unsigned)W;
     const bool mbA = x > 0;
     const int slot = x & 1;
     const int tile = tile_of(ts, g, x);
