@@ -102,6 +102,10 @@ SYMBOLS = {
     "dryv_recon_submit_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     "dryv_recon_sync": (C.c_int, [C.c_void_p]),
+    "dryv_recon_submit_device_queued": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]),
+    "dryv_recon_kernel_ms_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                             C.POINTER(C.c_float)]),
     "dryv_recon_output_bytes": (C.c_size_t, [C.POINTER(FrameParams), C.POINTER(OutputDesc)]),
     "dryv_recon_pack_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.POINTER(OutputDesc),
                                          C.c_void_p]),

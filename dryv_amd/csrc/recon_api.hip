@@ -25,7 +25,11 @@ using dryv::params::build_params;
 struct dryv_recon_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // the pair around the most recent timed launch (one of ev_ring)
+  // a ring of event pairs: launches queued back to back (dryv_recon_submit_device_queued) are timed one by one
+  static constexpr unsigned kEvRing = 64;
+  hipEvent_t ev_ring[kEvRing][2] = {};
+  unsigned ev_n = 0;   // timed launches recorded so far
   unsigned* d_status = nullptr;
   unsigned* h_status = nullptr;  // pinned
   // host-buffer path: grow-only device staging
@@ -57,6 +61,9 @@ struct dryv_recon_ctx {
   void* last_yuv = nullptr;
   bool last_band = false;
   int wide_reruns = 0;
+  // device-resident batches queued since the last sync (dryv_recon_submit_device_queued): kept for the wide re-run
+  struct Queued { KParams P; const void* mbs; const void* coeffs; void* yuv; };
+  std::vector<Queued> queued;
   // pipelined host path (dryv_recon_submit_host): copy-in and copy-out streams, per-chunk events
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<hipEvent_t> ev_in, ev_k;
@@ -97,6 +104,13 @@ size_t workspace_bytes(const KParams& P) {
   return b;
 }
 
+// the event pair the next timed launch records
+void next_events(dryv_recon_ctx* ctx) {
+  const unsigned k = ctx->ev_n++ % dryv_recon_ctx::kEvRing;
+  ctx->ev_start = ctx->ev_ring[k][0];
+  ctx->ev_stop = ctx->ev_ring[k][1];
+}
+
 int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, bool wide) {
   hipError_t e;
   const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
@@ -110,6 +124,7 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_profile_offset(P), 0, (size_t)65536 * 16 * 8 + (size_t)65536 * 32 * 2, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(profile)");
 #endif
+  next_events(ctx);
   e = hipEventRecord(ctx->ev_start, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
   e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, ctx->stream);
@@ -174,7 +189,15 @@ int finish(dryv_recon_ctx* ctx) {
     ctx->last_band = true;
     e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
     if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
-    int st = launch_band(ctx, ctx->last_P, ctx->last_mbs, ctx->last_coeffs, ctx->last_yuv, true);
+    int st = DRYV_OK;
+    if (ctx->queued.size() > 1) {
+      // several batches were queued behind each other and the status word does not say which of them raised the flag:
+      // all of them again with the wide build, in order
+      for (const dryv_recon_ctx::Queued& q : ctx->queued)
+        if ((st = launch_band(ctx, q.P, q.mbs, q.coeffs, q.yuv, true)) != DRYV_OK) break;
+    } else {
+      st = launch_band(ctx, ctx->last_P, ctx->last_mbs, ctx->last_coeffs, ctx->last_yuv, true);
+    }
     if (st != DRYV_OK) return st;
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
@@ -189,10 +212,11 @@ int finish(dryv_recon_ctx* ctx) {
   return DRYV_OK;
 }
 
-int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv) {
+int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, bool reset_status = true) {
   int st = ensure(ctx, &ctx->d_work, &ctx->cap_work, workspace_bytes(P));
   if (st != DRYV_OK) return st;
-  hipError_t e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
+  hipError_t e = hipSuccess;
+  if (reset_status) e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
   // Persistent grid: 32 waves per CU (8 per SIMD at 64 VGPRs); each band slot of a workgroup keeps claiming 4-row
   // bands until none are left, so a smaller grid is merely slower and never incorrect.
@@ -210,6 +234,7 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   if (grid < 1) grid = 1;
   e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+  next_events(ctx);
   e = hipEventRecord(ctx->ev_start, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
   e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
@@ -250,13 +275,19 @@ int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
   ctx->device = device_ordinal;
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
       (e = hipMalloc((void**)&ctx->d_status, 16)) != hipSuccess ||
       (e = hipHostMalloc((void**)&ctx->h_status, 16, hipHostMallocDefault)) != hipSuccess) {
     dryv_recon_destroy(ctx);
     return DRYV_E_DEVICE;
   }
   *ctx->h_status = 0;
+  for (unsigned k = 0; k < dryv_recon_ctx::kEvRing; k++)
+    if ((e = hipEventCreate(&ctx->ev_ring[k][0])) != hipSuccess || (e = hipEventCreate(&ctx->ev_ring[k][1])) != hipSuccess) {
+      dryv_recon_destroy(ctx);
+      return DRYV_E_DEVICE;
+    }
+  ctx->ev_start = ctx->ev_ring[0][0];
+  ctx->ev_stop = ctx->ev_ring[0][1];
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
@@ -280,8 +311,9 @@ void dryv_recon_destroy(dryv_recon_ctx* ctx) {
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
-  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  for (unsigned k = 0; k < dryv_recon_ctx::kEvRing; k++)
+    for (int j = 0; j < 2; j++)
+      if (ctx->ev_ring[k][j]) (void)hipEventDestroy(ctx->ev_ring[k][j]);
   for (hipEvent_t ev : ctx->ev_in) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->ev_k) (void)hipEventDestroy(ev);
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
@@ -520,6 +552,50 @@ int dryv_recon_submit_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, u
   return DRYV_OK;
 }
 
+int dryv_recon_submit_device_queued(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, const void* d_mbs,
+                                    const void* d_coeffs, void* d_yuv_out) {
+  if (!ctx || !d_mbs || !d_coeffs || !d_yuv_out || n_frames == 0) return DRYV_E_INVALID;
+  if (((uintptr_t)d_mbs | (uintptr_t)d_coeffs | (uintptr_t)d_yuv_out) & 15u) return DRYV_E_INVALID;
+  // behind batches of its own kind only: anything else in flight owns the context until it has been waited for
+  if (ctx->in_flight && ctx->queued.empty()) return DRYV_E_STATE;
+  KParams P;
+  int st = build_params(fp, n_frames, &P);
+  if (st != DRYV_OK) return st;
+  // the workspace is shared by the queued launches (each resets it on the stream, behind its predecessor); it cannot be
+  // re-allocated while one of them may still be running
+  if (ctx->in_flight && workspace_bytes(P) > ctx->cap_work) return DRYV_E_STATE;
+  (void)hipSetDevice(ctx->device);
+  // the status word is cleared in front of the first batch and accumulates over the queue
+  if ((st = launch(ctx, P, d_mbs, d_coeffs, d_yuv_out, ctx->queued.empty())) != DRYV_OK) return st;
+  ctx->queued.push_back(dryv_recon_ctx::Queued{P, d_mbs, d_coeffs, d_yuv_out});
+  ctx->in_flight = true;
+  ctx->in_flight_host = false;
+  return DRYV_OK;
+}
+
+int dryv_recon_kernel_ms_stats(dryv_recon_ctx* ctx, uint32_t n_last, float* avg_ms, float* min_ms, float* max_ms) {
+  if (!ctx || n_last == 0) return DRYV_E_INVALID;
+  if (!ctx->timed || ctx->in_flight) return DRYV_E_STATE;   // after wait / sync
+  const unsigned n = std::min(std::min((unsigned)n_last, ctx->ev_n), dryv_recon_ctx::kEvRing);
+  if (n == 0) return DRYV_E_STATE;
+  double sum = 0;
+  float mn = 0, mx = 0;
+  for (unsigned k = 0; k < n; k++) {
+    const unsigned idx = (ctx->ev_n - 1 - k) % dryv_recon_ctx::kEvRing;
+    float ms = 0;
+    hipError_t e = hipEventSynchronize(ctx->ev_ring[idx][1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev_ring[idx][0], ctx->ev_ring[idx][1]);
+    if (e != hipSuccess) return fail(ctx, e, "hipEventElapsedTime");
+    sum += ms;
+    mn = k == 0 ? ms : std::min(mn, ms);
+    mx = k == 0 ? ms : std::max(mx, ms);
+  }
+  if (avg_ms) *avg_ms = (float)(sum / n);
+  if (min_ms) *min_ms = mn;
+  if (max_ms) *max_ms = mx;
+  return DRYV_OK;
+}
+
 int dryv_recon_sync(dryv_recon_ctx* ctx) {
   if (!ctx) return DRYV_E_INVALID;
   (void)hipSetDevice(ctx->device);
@@ -539,6 +615,7 @@ int dryv_recon_sync(dryv_recon_ctx* ctx) {
     return DRYV_OK;
   }
   const int st = finish(ctx);
+  ctx->queued.clear();
   if (!ctx->in_flight_host) ctx->in_flight = false;
   if (st != DRYV_OK) return st;
   return (*ctx->h_status & 1u) ? DRYV_E_UNSUPPORTED : DRYV_OK;

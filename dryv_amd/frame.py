@@ -165,6 +165,18 @@ class ReconContext:
         _check(self._lib.dryv_recon_submit_device(self._h, C.byref(fp), int(n_frames), C.c_void_p(d_mbs),
                                                   C.c_void_p(d_coeffs), C.c_void_p(d_yuv_out)), self._h)
 
+    def submit_device_queued(self, fp, n_frames, d_mbs, d_coeffs, d_yuv_out):
+        """dryv_recon_submit_device_queued: like submit_device, but may be called again before sync(); the batches run back
+        to back on the stream."""
+        _check(self._lib.dryv_recon_submit_device_queued(self._h, C.byref(fp), int(n_frames), C.c_void_p(d_mbs),
+                                                         C.c_void_p(d_coeffs), C.c_void_p(d_yuv_out)), self._h)
+
+    def kernel_ms_stats(self, n_last):
+        """(average, minimum, maximum) device time in ms of the n_last most recent reconstruction launches (<= 64)."""
+        a, lo, hi = C.c_float(), C.c_float(), C.c_float()
+        _check(self._lib.dryv_recon_kernel_ms_stats(self._h, int(n_last), C.byref(a), C.byref(lo), C.byref(hi)), self._h)
+        return float(a.value), float(lo.value), float(hi.value)
+
     def sync(self, allow_unsupported=False):
         st = self._lib.dryv_recon_sync(self._h)
         if not (allow_unsupported and st == abi.DRYV_E_UNSUPPORTED):

@@ -135,6 +135,15 @@ int dryv_recon_submit_device(dryv_recon_ctx *ctx, const dryv_frame_params *fp, u
                              const void *d_mbs, const void *d_coeffs, void *d_yuv_out);
 int dryv_recon_sync(dryv_recon_ctx *ctx); /* waits, then reports the batch's status word */
 
+/* The same, queued: may be called again before dryv_recon_sync, any number of times, each call with buffers of its own;
+ * the batches run back to back on the context's stream with no host round trip between them (a decoder that fills
+ * batch k+1 while batch k reconstructs: the reference's per-picture loop, decoder.rs:124-143, made asynchronous).
+ * dryv_recon_sync then waits for all of them and reports the OR of their status words; every queued batch's inputs
+ * must stay valid until it returns. Only behind queued batches: DRYV_E_STATE if anything else is in flight, or if this
+ * batch would need a larger workspace than the queue is running on (sync first). */
+int dryv_recon_submit_device_queued(dryv_recon_ctx *ctx, const dryv_frame_params *fp, uint32_t n_frames,
+                                    const void *d_mbs, const void *d_coeffs, void *d_yuv_out);
+
 /* ---- output stage: cropping and NV12 packing on the device ------------------------------------------
  * The reference parses frame_crop_*_offset (sps.rs:252-267) but writes the full coded planes (frame/mod.rs:48-70;
  * README.md:13 unchecked), which stays this library's default output. A caller that wants display-size pictures, or
@@ -180,6 +189,10 @@ int dryv_recon_wait_filtered(dryv_recon_ctx *ctx, const dryv_deblock_params *dp,
 /* Device time of the most recent reconstruction kernel launch, from HIP events recorded on the
  * context's own stream immediately around the launch. Valid after wait/sync. */
 int dryv_recon_last_kernel_ms(dryv_recon_ctx *ctx, float *ms);
+/* Average / minimum / maximum device time of the n_last most recent reconstruction kernel launches (at most 64 are
+ * remembered; every launch is bracketed by an event pair of its own, so queued launches are timed one by one). Any of the
+ * three pointers may be NULL. Valid after wait/sync. */
+int dryv_recon_kernel_ms_stats(dryv_recon_ctx *ctx, uint32_t n_last, float *avg_ms, float *min_ms, float *max_ms);
 
 /* Raw HIP stream handle (hipStream_t) the context launches on, for callers that want to order
  * their own work or record their own events against it. */

@@ -222,6 +222,48 @@ def test_device_resident_path(recon_ctx):
     assert np.array_equal(d_o.cpu().numpy(), want)
 
 
+def test_queued_device_submits(recon_ctx):
+    """dryv_recon_submit_device_queued: several batches behind each other on the stream, one sync (what bench.py times).
+    Three different batches of different sizes into buffers of their own; then a queue in which the middle batch has
+    coefficients beyond the 32-bit path's bound, so that the whole queue is re-run with the wide build at sync. Every
+    picture must equal the oracle's, the launches are timed one by one, and nothing else may be submitted meanwhile."""
+    import torch
+    fp = abi.make_frame_params(11, 9)
+    cases = []
+    for k, (frames, big) in enumerate([(5, False), (4, True), (2, False)]):   # (the first batch sizes the queue's workspace)
+        cfg = synth.config(i4x4=0.6, qp=(51, 51), coded=1.0) if big else synth.config(i4x4=0.6)
+        mbs, co = synth.generate(fp, cfg, 300 + k, 0, frames)
+        if big:
+            co = np.where(np.arange(co.size).reshape(co.shape) % 2 == 0, 32767, -32768).astype(np.int16)
+        cases.append((frames, mbs, co))
+    for use in ([0, 2, 0], [0, 1, 2]):   # without / with the batch that needs the wide re-run
+        bufs = []
+        for k in use:
+            frames, mbs, co = cases[k]
+            d_m = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda()
+            d_c = torch.from_numpy(co).cuda()
+            d_o = torch.zeros(frames * 99 * 384, dtype=torch.uint8, device="cuda")
+            bufs.append((k, d_m, d_c, d_o))
+        torch.cuda.synchronize()
+        for k, d_m, d_c, d_o in bufs:
+            recon_ctx.submit_device_queued(fp, cases[k][0], d_m.data_ptr(), d_c.data_ptr(), d_o.data_ptr())
+        with pytest.raises(ReconError) as e:   # a batch of another kind cannot cut in
+            recon_ctx.submit_device(fp, cases[0][0], bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr())
+        assert e.value.status == abi.DRYV_E_STATE
+        if use[0] == 0:   # ... nor one that needs a larger workspace than the queue runs on
+            fpl = abi.make_frame_params(40, 30)
+            with pytest.raises(ReconError) as e:
+                recon_ctx.submit_device_queued(fpl, 8, bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr())
+            assert e.value.status == abi.DRYV_E_STATE
+        recon_ctx.sync()
+        avg, lo, hi = recon_ctx.kernel_ms_stats(len(bufs))
+        assert 0 < lo <= avg <= hi
+        for k, d_m, d_c, d_o in bufs:
+            frames, mbs, co = cases[k]
+            st, want = oracle.reconstruct(fp, frames, mbs, co)
+            assert st == 0 and np.array_equal(d_o.cpu().numpy(), want), "queued batch %d" % k
+
+
 # ---- BASELINE.json full sizes: golden digest of one frame + size-independent properties --------
 def _digest(a):
     return hashlib.sha256(a.tobytes()).hexdigest()
