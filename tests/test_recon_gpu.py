@@ -250,11 +250,6 @@ def test_queued_device_submits(recon_ctx):
         with pytest.raises(ReconError) as e:   # a batch of another kind cannot cut in
             recon_ctx.submit_device(fp, cases[0][0], bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr())
         assert e.value.status == abi.DRYV_E_STATE
-        if use[0] == 0:   # ... nor one that needs a larger workspace than the queue runs on
-            fpl = abi.make_frame_params(40, 30)
-            with pytest.raises(ReconError) as e:
-                recon_ctx.submit_device_queued(fpl, 8, bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr())
-            assert e.value.status == abi.DRYV_E_STATE
         recon_ctx.sync()
         avg, lo, hi = recon_ctx.kernel_ms_stats(len(bufs))
         assert 0 < lo <= avg <= hi
@@ -262,6 +257,35 @@ def test_queued_device_submits(recon_ctx):
             frames, mbs, co = cases[k]
             st, want = oracle.reconstruct(fp, frames, mbs, co)
             assert st == 0 and np.array_equal(d_o.cpu().numpy(), want), "queued batch %d" % k
+
+
+def test_queue_cannot_outgrow_its_workspace():
+    """A queued batch that needs a larger workspace than the queue is running on is refused (DRYV_E_STATE: sync first), not
+    launched: a context of its own, so that the workspace is known to be the first batch's; every buffer is full size."""
+    import torch
+    from dryv_amd.frame import ReconContext
+    small, large = abi.make_frame_params(6, 5), abi.make_frame_params(40, 30)
+    with ReconContext(0) as ctx:
+        bufs = []
+        for fp, frames in ((small, 2), (large, 8)):
+            mbs, co = synth.generate(fp, synth.config(), 77, 0, frames)
+            per = fp.pic_width_in_mbs * fp.pic_height_in_mbs
+            bufs.append((fp, frames, mbs, co, torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda(), torch.from_numpy(co).cuda(),
+                         torch.zeros(frames * per * 384, dtype=torch.uint8, device="cuda")))
+        torch.cuda.synchronize()
+        fp, frames, mbs, co, d_m, d_c, d_o = bufs[0]
+        ctx.submit_device_queued(fp, frames, d_m.data_ptr(), d_c.data_ptr(), d_o.data_ptr())
+        fpl, fl, mbl, col, d_ml, d_cl, d_ol = bufs[1]
+        with pytest.raises(ReconError) as e:
+            ctx.submit_device_queued(fpl, fl, d_ml.data_ptr(), d_cl.data_ptr(), d_ol.data_ptr())
+        assert e.value.status == abi.DRYV_E_STATE
+        ctx.sync()
+        st, want = oracle.reconstruct(fp, frames, mbs, co)
+        assert np.array_equal(d_o.cpu().numpy(), want)
+        ctx.submit_device_queued(fpl, fl, d_ml.data_ptr(), d_cl.data_ptr(), d_ol.data_ptr())   # after the sync it may grow
+        ctx.sync()
+        st, want = oracle.reconstruct(fpl, fl, mbl, col)
+        assert np.array_equal(d_ol.cpu().numpy(), want)
 
 
 # ---- BASELINE.json full sizes: golden digest of one frame + size-independent properties --------
