@@ -944,13 +944,17 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
         const int Lb = wv::dpp<DPP_ROW_SHL(3)>(Mprev, Mprev);
         const bool unav = (rbx == 0 && !mbA) || (rby == 0 && !mbB);
+        // Neighbours as one min3 of DPP operands (modes are 0..8, 15 stands for "none"):
+        //   B: the lane one grid row up; grid row 0 (lanes 0..3 of the DPP row: no source, reads 0) takes Tb by an OR
+        //   A: the lane to the left; column 0 gets its own lane by the quad permute, which an OR with 15 turns into "none",
+        //      and takes the macroblock to the left (or 2) through the third operand
+        const int TbTop = rby == 0 ? Tb : 0, col0 = rbx == 0 ? 15 : 0, Aout = rbx == 0 ? (mbA ? Lb : 2) : 15;
         int M = 2;
 #pragma unroll
         for (int itr = 0; itr < 7; itr++) {
-          int Am = wv::dppx<DPP_QUAD(0, 0, 1, 2)>(M);
-          if (rbx == 0) Am = mbA ? Lb : 2;
-          const int Bm = wv::dpp<DPP_ROW_SHR(4)>(Tb, M);  // lanes 0..3 of the row keep Tb
-          const int pm = unav ? 2 : min(Am, Bm);
+          const int Am = wv::dppx<DPP_QUAD(0, 0, 1, 2)>(M) | col0;
+          const int Bm = wv::dppz<DPP_ROW_SHR(4)>(M) | TbTop;
+          const int pm = unav ? 2 : min(min(Am, Bm), Aout);
           M = prev ? pm : (rem < pm ? rem : rem + 1);
           if (HAS_I8) {
             const int t = wv::dppx<DPP_QUAD(0, 0, 2, 2)>(M);        // the even column's value

@@ -37,6 +37,9 @@ WV int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL
 // move into the instruction that uses it
 template <int CTRL>
 WV int dppx(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xF, 0xF, true); }
+// the same for controls under which some lanes have no source (row_shr / row_shl): those lanes get 0 (bound_ctrl)
+template <int CTRL>
+WV int dppz(int src) { return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xF, 0xF, true); }
 // lanes 32..63 of a <-> lanes 0..31 of b (v_permlane32_swap_b32)
 WV void swap32(unsigned& a, unsigned& b) {
   const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -200,6 +203,8 @@ WV int dpp(int old, int src) {
 }
 template <int CTRL>
 WV int dppx(int src) { return dpp<CTRL>(src, src); }
+template <int CTRL>
+WV int dppz(int src) { return dpp<CTRL>(0, src); }
 WV void swap32(unsigned& a, unsigned& b) {
   const int l = lane_id();
   g_emu.xbuf[l] = (int)(l < 32 ? b : a);  // what this lane gives away
