@@ -792,8 +792,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       const int i16mode = (int)((dCur.x >> 8) & 0xffu), cmodeL = (int)((dCur.x >> 16) & 0xffu);
       int qp = (int)(dCur.x >> 24);
       const unsigned prevFlags = dCur.y & 0xffffu;
-      const unsigned long long remBits = ((unsigned long long)(dCur.y >> 16)) | ((unsigned long long)dCur.z << 16) |
-                                         ((unsigned long long)(dCur.w & 0xffffu) << 48);
+      // the sixteen 4-bit rem fields (bytes 6..13 of the record) as two words: fields 0..7, 8..15
+      const unsigned remLo = wv::alignbit(dCur.z, dCur.y, 16), remHi = wv::alignbit(dCur.w, dCur.z, 16);
       if (kind > 2 || (!HAS_I8 && kind == 1) || qp > 51 || i16mode > 3 || cmodeL > 3) {
         if (valid && i == 0) wv::atomic_or(A.status, 1u);
         kind = 3;
@@ -938,7 +938,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       if (anyI4) {
         const bool is8 = HAS_I8 && kind == 1;
         const int mzb = is8 ? 2 * (rby >> 1) + (rbx >> 1) : hMzb4 >> 2;
-        const int rem = (int)((remBits >> (4 * mzb)) & 7ull);
+        const int rem = (int)(((mzb < 8 ? remLo : remHi) >> (4 * (mzb & 7))) & 7u);
         const bool prev = ((prevFlags >> mzb) & 1u) != 0;
         const unsigned upM = mbB ? wv::lds_u32(ts + S_RINGM + 16 * g + 4 * (x & 3)) : 0x02020202u;
         const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
