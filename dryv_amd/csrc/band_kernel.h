@@ -575,10 +575,9 @@ WV void residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp,
 }
 
 // lane i ^ 4 and i ^ 8 inside a 16-lane DPP row
-WV int xor4(int v, bool bit2) {
-  const int a = wv::dppx<DPP_ROW_ROR(12)>(v), b = wv::dppx<DPP_ROW_ROR(4)>(v);
-  return bit2 ? b : a;
-}
+// (i ^ 4 = the quads of every eight lanes swapped = the eight mirrored, then every quad mirrored back: two DPP moves, the
+// second of which the compiler folds into the instruction that uses it; no select)
+WV int xor4(int v, bool) { return wv::dppx<DPP_QUAD(3, 2, 1, 0)>(wv::dppx<DPP_ROW_HALF_MIRROR>(v)); }
 WV int xor8(int v) { return wv::dppx<DPP_ROW_ROR(8)>(v); }
 WV int xor1(int v) { return wv::dppx<DPP_QUAD(1, 0, 3, 2)>(v); }
 WV int xor2(int v) { return wv::dppx<DPP_QUAD(2, 3, 0, 1)>(v); }

@@ -16,6 +16,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define DPP_ROW_SHL(n) (0x100 + (n))
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_ROW_ROR(n) (0x120 + (n))
+#define DPP_ROW_HALF_MIRROR 0x141   // lane i of every eight <- lane 7 - i
 
 #ifndef DRYV_EMU
 // =====================================================================================================
@@ -188,6 +189,7 @@ WV int emu_dpp_src(int ctrl, int lane) {
   if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl - 0x100; return i + n <= 15 ? row + i + n : -1; }
   if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; return i - n >= 0 ? row + i - n : -1; }
   if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl - 0x120; return row + ((i - n) & 15); }
+  if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));
   fprintf(stderr, "emu: unsupported dpp ctrl %x\n", ctrl);
   abort();
 }
