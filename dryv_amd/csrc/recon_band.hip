@@ -35,21 +35,24 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5
   // consecutive waves of a workgroup go to different SIMDs: a team's three waves never share one
   const int team = wave / band::WAVES_PER_TEAM, role = wave - team * band::WAVES_PER_TEAM;
   const int ts = ldsBase + tEnd + team * band::team_bytes(HAS_I8);
-  // Wave priority by role (s_setprio: the SIMD's arbiter prefers the higher one when several waves can issue): BACK is
-  // the wave on a band's critical path -- every other wave of the team, and the band below, wait for it -- so it goes
-  // first. Measured on the 300-picture batch, alternating on one box: none 1.444 ms, BACK 1: 1.42, BACK 2: 1.388,
-  // BACK 3: 1.397; FRONT raised as well, or alone: no gain (1.47).
+  // Wave priority by role (s_setprio: the SIMD's arbiter prefers the higher one when several waves can issue). FRONT is a
+  // producer that runs up to two steps ahead of the other two; BACK is the wave on a band's critical path, and CHROMA's
+  // bottom lines are what the band below's CHROMA waits for: the two consumers go first. Measured on the 300-picture
+  // batch (tools/band_variants.sh, same box within a line): no priorities 1.444 ms / BACK 2: 1.388 / BACK 3: 1.397;
+  // BACK 2: 1.433 / BACK 2 + CHROMA 1: 1.373 / BACK = CHROMA = 2: 1.336-1.370 / 1, 1: 1.335-1.371 / 3, 2: 1.335-1.370;
+  // FRONT raised with them, or alone: 1.47-1.49 (no gain or worse).
 #ifndef DRYV_BAND_PRIO_BACK
 #define DRYV_BAND_PRIO_BACK 2
+#endif
+#ifndef DRYV_BAND_PRIO_CHROMA
+#define DRYV_BAND_PRIO_CHROMA 2
 #endif
 #ifndef DRYV_BAND_PRIO_FRONT
 #define DRYV_BAND_PRIO_FRONT 0
 #endif
   if (role == 1 && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
+  if (role == 2 && DRYV_BAND_PRIO_CHROMA) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_CHROMA);
   if (role == 0 && DRYV_BAND_PRIO_FRONT) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_FRONT);
-#ifdef DRYV_BAND_PRIO_CHROMA
-  if (role == 2) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_CHROMA);
-#endif
   if (role == 1) band::band_back<HAS_I8>(P, A, ldsBase, ts);
   else if (role == 0) band::band_front<HAS_I8, WIDE>(P, A, ldsBase, ts);
   else band::band_chroma<HAS_I8, WIDE>(P, A, ldsBase, ts);
