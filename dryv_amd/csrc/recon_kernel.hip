@@ -480,6 +480,17 @@ recon_kernel(const KParams P, const dryv_mb_desc* __restrict__ mbs, const int16_
   const int wgWave = rfl(threadIdx.x >> 6);
   const int wave = wgWave & (BAND - 1);  // position in the band
   const int W = P.W, H = P.H;
+  // Wave priority = position in the band (s_setprio): a row waits for the row above it, so the consumer goes first when
+  // both can issue (the same observation as for the band kernel's roles, recon_band.hip). C3 (100 x 4K, 8x8 transform):
+  // no priorities 3.92 ms, the upper rows first 3.82-3.83, the lower rows first 3.77.
+#ifndef DRYV_ROW_PRIO
+#define DRYV_ROW_PRIO 1
+#endif
+  if (DRYV_ROW_PRIO) {
+    if (wave == 3) __builtin_amdgcn_s_setprio(3);
+    else if (wave == 2) __builtin_amdgcn_s_setprio(2);
+    else if (wave == 1) __builtin_amdgcn_s_setprio(1);
+  }
 
   // ---- LDS tables (built once per workgroup) -------------------------------------------------------
   unsigned* lsq = (unsigned*)(lds + LT_LSQ);
