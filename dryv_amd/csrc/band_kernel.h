@@ -128,6 +128,14 @@ constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a progress word (about a second) before a band gives up
 constexpr unsigned TASK_END = 0xFFFFFFFFu;
 
+// Analysis only (tools/band_ablate.sh): -DDRYV_BAND_EXP_SKIP=<mask> drops phase k of the step (bit k) so that the difference
+// in SQ_INSTS_VALU against the full kernel is that phase's dynamic instruction count. Such a build reconstructs wrong
+// pictures; the shipped library is built with mask 0 and contains none of it.
+#ifndef DRYV_BAND_EXP_SKIP
+#define DRYV_BAND_EXP_SKIP 0
+#endif
+#define EXP_SKIP(k) ((((DRYV_BAND_EXP_SKIP) >> (k)) & 1) != 0)
+
 // Diagnostic builds only. -DDRYV_BAND_PROFILE (tools/band_phases.py): per-wave cycle sums per phase of the step.
 // -DDRYV_BAND_TRACE (tools/band_trace.py): breadcrumbs only. Both write to a buffer of their own; the shipped library
 // contains none of this.
@@ -806,7 +814,10 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       PH(1);  // record decode
       // ================= residuals ================================================================================
       unsigned rA[8];
-      {
+      if (EXP_SKIP(0)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) rA[k] = cA0.x;
+      } else {
         // Intra16x16 luma DC: 8.5.10 (pred16x16.rs:428-482). Lane (bx,by) holds c[by][bx]; f = A c A = P (H c H) P^T
         // with H the natural-order Hadamard (butterflies over the lane bits) and A row k = H row s(k), s = [0,2,3,1]
         long long dcY = 0;
@@ -869,7 +880,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         return v;
       };
       bool haveNext = false;
-      if (needUp) {
+      if (needUp && !EXP_SKIP(2)) {
         // the band above must have finished macroblock s+1 (luma: BACK's neighbour C; modes) before they are fetched.
         // Its progress words are read one step ahead (flagV), so this normally costs nothing; otherwise poll.
         if (flagPend) upKnown = max(upKnown, min((unsigned)wv::rfl((int)flagV), (unsigned)wv::rdlane((int)flagV, 32)));
@@ -933,7 +944,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       // Intra8x8 (8.3.2.1, pred8x8.rs:698-764): each 8x8 block fills its four grid positions with its mode; the block's
       // top-left position derives it exactly like a 4x4 block there would (its A is the position left of the block's
       // first row, its B the one above its first column), the other three copy it after every sweep.
-      const bool anyI4 = wv::any(valid && (kind == 0 || (HAS_I8 && kind == 1)));
+      const bool anyI4 = !EXP_SKIP(1) && wv::any(valid && (kind == 0 || (HAS_I8 && kind == 1)));
       if (anyI4) {
         const bool is8 = HAS_I8 && kind == 1;
         const int mzb = is8 ? 2 * (rby >> 1) + (rbx >> 1) : hMzb4 >> 2;
@@ -1158,7 +1169,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         return wv::ld_sc1((const unsigned*)(planeY + (oUp + (unsigned)((8 * r0 - 1) * pitchC + 8 * mb))));
       };
       bool haveNext = false;
-      if (needUp) {
+      if (needUp && !EXP_SKIP(9)) {
         if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
         flagPend = false;
         upKnown = poll_progress(upProg, upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
@@ -1178,7 +1189,10 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       PH(1);  // hand-off traffic
 
       // ================= chroma residuals ==========================================================================
-      if (evenStep) {
+      if (evenStep && EXP_SKIP(6)) {
+        load_coefs_chroma(s + 2);
+        kN1 = load_kind(s + 2);
+      } else if (evenStep) {
         // chroma DC 2x2 (8.5.11, trans_chroma.rs:369-415) over the four block lanes of a plane, then the AC pass.
         // The LevelScale table is luma's (quirk Q3).
         const int qc = (int)wv::lds_u8(ldsBase + T_QPC + 52 * cpl + qpR);
@@ -1209,7 +1223,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       PH(2);  // chroma residuals, prefetch
 
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (block half, row gc, plane, block) =======
-      {
+      if (!EXP_SKIP(7)) {
         const unsigned dP = evenStep ? dEven : dOdd;
         const int kindC = (int)(dP & 0xffu), cmode = (int)((dP >> 16) & 0xffu);
         const int ringP = ts + S_RINGC + RINGC_ROW * gc + 8 * cpl;
@@ -1330,7 +1344,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       wv::wave_sync();
       // flush the staged rows: every NSC-th macroblock, or at the end of a row: 8 * NSC contiguous bytes per pixel row.
       // The bottom lines of a band that has a band below were already written through.
-      if (wv::any(valid && (slot == NSC - 1 || x == W - 1))) {
+      if (!EXP_SKIP(8) && wv::any(valid && (slot == NSC - 1 || x == W - 1))) {
         constexpr int LR = 8 * NSC;  // lanes per macroblock row: 2 planes x 8 pixel rows x NSC / 2 segments of 16 bytes
 #pragma unroll
         for (int it = 0; it < NSC / 2; it++) {
@@ -1448,7 +1462,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     PH(1);  // top border
 
       // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
-      if (wv::any(valid && kind >= 2)) {
+      if (!EXP_SKIP(3) && wv::any(valid && kind >= 2)) {
         const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
         const unsigned lw = wv::lds_u32(ts + S_LEFTY + 16 * g + 4 * zby);
         unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
@@ -1539,7 +1553,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         linePend = false;
       }
       PH(3);  // top-right copy, publish
-      const bool anyI4 = wv::any(valid && kind == 0);
+      const bool anyI4 = !EXP_SKIP(4) && wv::any(valid && kind == 0);
 
       // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================
       // lane = (row g, block half ch, pixel pair cp). Rounds with two blocks per macroblock (2..7): pixels
@@ -1760,7 +1774,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       wv::wave_sync();
       // flush the staged rows: every NSY-th macroblock, or at the end of a row: 16 * NSY contiguous bytes per pixel row.
       // The bottom line of a band that has a band below was already written through.
-      if (wv::any(valid && ((x & (NSY - 1)) == NSY - 1 || x == W - 1))) {
+      if (!EXP_SKIP(5) && wv::any(valid && ((x & (NSY - 1)) == NSY - 1 || x == W - 1))) {
         constexpr int LR = 16 * NSY;  // lanes per macroblock row: 16 pixel rows x NSY segments of 16 bytes
 #pragma unroll
         for (int it = 0; it < NSY; it++) {

@@ -3,7 +3,26 @@
 
 #include <stdlib.h>
 
+#include <memory>
+#include <new>
+
 using namespace dryv::h264;
+
+// Nothing may leave an extern "C" function by exception: the parser's own Error, and whatever the standard library
+// throws underneath it (bad_alloc from a vector sized by a stream's parameters, length_error ...), all end as a message.
+#define DRYV_CATCH_ALL(ret)                                    \
+  catch (const Error& e) {                                     \
+    g_err = e.what;                                            \
+    return ret;                                                \
+  }                                                            \
+  catch (const std::exception& e) {                            \
+    g_err = std::string("host parser: ") + e.what();           \
+    return ret;                                                \
+  }                                                            \
+  catch (...) {                                                \
+    g_err = "host parser: unknown exception";                  \
+    return ret;                                                \
+  }
 
 extern "C" {
 
@@ -17,13 +36,11 @@ struct dryv_h264_frame {
 static thread_local std::string g_err;
 dryv_h264_frame* dryv_h264_parse(const uint8_t* data, size_t n) {
   try {
-    dryv_h264_frame* h = new dryv_h264_frame();
+    std::unique_ptr<dryv_h264_frame> h(new dryv_h264_frame());
     h->F = parse_first_islice(data, n);
-    return h;
-  } catch (const Error& e) {
-    g_err = e.what;
-    return nullptr;
+    return h.release();
   }
+  DRYV_CATCH_ALL(nullptr)
 }
 const char* dryv_h264_last_error(void) { return g_err.c_str(); }
 void dryv_h264_free(dryv_h264_frame* h) { delete h; }
@@ -59,10 +76,8 @@ long long dryv_h264_encode_idr(const dryv_frame_params* fp, const dryv_mb_desc* 
     if (v.size() > cap) return -(long long)v.size();
     memcpy(out, v.data(), v.size());
     return (long long)v.size();
-  } catch (const Error& e) {
-    g_err = e.what;
-    return 0;
   }
+  DRYV_CATCH_ALL(0)
 }
 
 /* The same with a frame cropping rectangle (luma samples: left, right, top, bottom; even) in the SPS. */
@@ -73,10 +88,8 @@ long long dryv_h264_encode_idr_cropped(const dryv_frame_params* fp, const dryv_m
     if (v.size() > cap) return -(long long)v.size();
     memcpy(out, v.data(), v.size());
     return (long long)v.size();
-  } catch (const Error& e) {
-    g_err = e.what;
-    return 0;
   }
+  DRYV_CATCH_ALL(0)
 }
 
 /* ---- batches of pictures ------------------------------------------------------------------------------------------------ */
@@ -94,22 +107,19 @@ dryv_h264_batch* dryv_h264_parse_all(const uint8_t* data, size_t n, size_t max_p
 /* n_threads: pictures are parsed in parallel (0 = one thread per hardware thread) */
 dryv_h264_batch* dryv_h264_parse_all_mt(const uint8_t* data, size_t n, size_t max_pictures, unsigned n_threads) {
   try {
-    auto* b = new dryv_h264_batch;
+    std::unique_ptr<dryv_h264_batch> b(new dryv_h264_batch);
     b->F = parse_all_islices(data, n, max_pictures ? max_pictures : (size_t)-1, &b->skipped, n_threads);
     for (const ParsedFrame& f : b->F) {
       if (memcmp(&f.fp, &b->F[0].fp, sizeof(f.fp)) != 0) {
-        delete b;
         g_err = "pictures of different parameters in one stream";
         return nullptr;
       }
       b->mbs.insert(b->mbs.end(), f.mbs.begin(), f.mbs.end());
       b->coeffs.insert(b->coeffs.end(), f.coeffs.begin(), f.coeffs.end());
     }
-    return b;
-  } catch (const Error& e) {
-    g_err = e.what;
-    return nullptr;
+    return b.release();
   }
+  DRYV_CATCH_ALL(nullptr)
 }
 /* Parameter sets only: fills fp_out from the stream's first SPS / PPS and returns the number of coded slice NAL units
  * (an upper bound on the pictures parse_all will deliver); 0 on failure. Cheap: no slice data is decoded. */
@@ -117,13 +127,19 @@ long long dryv_h264_stream_params(const uint8_t* data, size_t n, dryv_frame_para
   try {
     const bool mp4 = n >= 12 && memcmp(data + 4, "ftyp", 4) == 0;
     const Stream S = mp4 ? demux_mp4(data, n, (size_t)-1) : demux_annexb(data, n);
-    if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
-    if (fp_out) set_flat_params(*fp_out, S.sps.width_mbs, S.sps.height_map_units, S.pps);
+    if (S.spsAll.empty() || S.ppsAll.empty()) fail("no SPS / PPS");
+    if (S.slices.empty()) fail("no coded slice");
+    // the parameter sets of the first picture parse_all will deliver (the first coded slice's, if none qualifies)
+    const Stream::Nal* first = &S.slices[0];
+    for (const Stream::Nal& nal : S.slices)
+      if (is_whole_picture_islice(nal.p, nal.n)) {
+        first = &nal;
+        break;
+      }
+    if (fp_out) set_params(*fp_out, S.sps_of(*first), S.pps_of(*first));
     return (long long)S.slices.size();
-  } catch (const Error& e) {
-    g_err = e.what;
-    return 0;
   }
+  DRYV_CATCH_ALL(0)
 }
 /* The same, with the records and coefficients written straight into the caller's batch buffers (e.g. page-locked memory from
  * dryv_recon_alloc_host: no intermediate copy), `capacity` pictures large. Returns the number of pictures, 0 on failure;
@@ -150,10 +166,8 @@ long long dryv_h264_parse_all_into(const uint8_t* data, size_t n, size_t max_pic
       info4[3] = 0;
     }
     return (long long)F.size();
-  } catch (const Error& e) {
-    g_err = e.what;
-    return 0;
   }
+  DRYV_CATCH_ALL(0)
 }
 void dryv_h264_batch_free(dryv_h264_batch* b) { delete b; }
 size_t dryv_h264_batch_pictures(const dryv_h264_batch* b) { return b->F.size(); }
@@ -178,10 +192,8 @@ long long dryv_h264_encode_stream(const dryv_frame_params* fp, int n_pictures, c
     if (v.size() > cap) return -(long long)v.size();
     memcpy(out, v.data(), v.size());
     return (long long)v.size();
-  } catch (const Error& e) {
-    g_err = e.what;
-    return 0;
   }
+  DRYV_CATCH_ALL(0)
 }
 
 }  // extern "C"

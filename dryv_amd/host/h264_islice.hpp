@@ -118,18 +118,87 @@ inline void append_nal_annexb(std::vector<uint8_t>& out, uint8_t header, const s
 }
 
 // ---- parameter sets ----------------------------------------------------------------------------------------------------
+// Scaling matrices as the reference decodes them (atom/avcc/sps.rs:150-250): entries in the order they are coded (zig-zag),
+// which is the order dryv_frame_params takes. Two things the reference does differently from 7.4.2.1.1 / 7.4.2.2 are kept,
+// because the output must be the reference's: a list whose scaling_list_present_flag is 0 becomes the Default_* table
+// (the standard's fall-back rules A / B would copy the previous list for lists 1, 2, 4, 5, 7..), and when both parameter
+// sets carry a matrix the SPS's wins (slice/header.rs:317-332; the standard lets the PPS's override it).
+struct ScalingLists {
+  bool present = false;
+  int n8 = 0;               // 8x8 lists carried (2 for 4:2:0)
+  uint8_t l4[6][16];
+  uint8_t l8[6][64];
+};
+static const uint8_t SL_DEFAULT_4X4[2][16] = {   // Table 7-3: Default_4x4_Intra, Default_4x4_Inter
+    {6, 13, 13, 20, 20, 20, 28, 28, 28, 28, 32, 32, 32, 37, 37, 42},
+    {10, 14, 14, 20, 20, 20, 24, 24, 24, 24, 27, 27, 27, 30, 30, 34}};
+static const uint8_t SL_DEFAULT_8X8[2][64] = {   // Table 7-4: Default_8x8_Intra, Default_8x8_Inter
+    {6,  10, 10, 13, 11, 13, 16, 16, 16, 16, 18, 18, 18, 18, 18, 23, 23, 23, 23, 23, 23, 25, 25, 25, 25, 25, 25, 25, 27, 27, 27, 27,
+     27, 27, 27, 27, 29, 29, 29, 29, 29, 29, 29, 31, 31, 31, 31, 31, 31, 33, 33, 33, 33, 33, 36, 36, 36, 36, 38, 38, 38, 40, 40, 42},
+    {9,  13, 13, 15, 13, 15, 17, 17, 17, 17, 19, 19, 19, 19, 19, 21, 21, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 24, 24, 24, 24,
+     24, 24, 24, 24, 25, 25, 25, 25, 25, 25, 25, 27, 27, 27, 27, 27, 27, 28, 28, 28, 28, 28, 30, 30, 30, 30, 32, 32, 32, 33, 33, 35}};
+// 7.3.2.1.1.1 scaling_list(): returns useDefaultScalingMatrixFlag (sps.rs:179-198)
+inline bool read_scaling_list(BitReader& r, uint8_t* out, int size) {
+  bool useDefault = false;
+  int last = 8, next = 8;
+  for (int j = 0; j < size; j++) {
+    if (next != 0) {
+      const int delta = r.se();
+      if (delta < -128 || delta > 127) fail("scaling list: delta_scale out of range");
+      next = (last + delta + 256) % 256;
+      useDefault = j == 0 && next == 0;
+    }
+    out[j] = (uint8_t)(next == 0 ? last : next);
+    last = out[j];
+  }
+  return useDefault;
+}
+inline ScalingLists read_scaling_matrix(BitReader& r, int n_lists) {   // sps.rs:206-249 (ScalingLists::new)
+  ScalingLists L;
+  L.present = true;
+  L.n8 = n_lists - 6;
+  memset(L.l4, 16, sizeof L.l4);
+  memset(L.l8, 16, sizeof L.l8);
+  for (int i = 0; i < n_lists; i++) {
+    const bool present = r.bit() != 0;
+    if (i < 6) {
+      if (!present || read_scaling_list(r, L.l4[i], 16)) memcpy(L.l4[i], SL_DEFAULT_4X4[i < 3 ? 0 : 1], 16);
+    } else {
+      if (!present || read_scaling_list(r, L.l8[i - 6], 64)) memcpy(L.l8[i - 6], SL_DEFAULT_8X8[(i & 1) ? 1 : 0], 64);
+    }
+  }
+  return L;
+}
+inline void write_scaling_list(BitWriter& w, const uint8_t* l, int size) {
+  int last = 8;
+  for (int j = 0; j < size; j++) {
+    if (l[j] == 0) fail("encoder: a scaling list entry of 0 cannot be coded");
+    int d = (int)l[j] - last;
+    if (d > 127) d -= 256;
+    if (d < -128) d += 256;
+    w.se(d);
+    last = l[j];
+  }
+}
+
 struct Sps {
-  int profile_idc = 0, level_idc = 0, chroma_format_idc = 1, bit_depth_luma = 8, bit_depth_chroma = 8;
+  int id = 0, profile_idc = 0, level_idc = 0, chroma_format_idc = 1, bit_depth_luma = 8, bit_depth_chroma = 8;
   int log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4;
   int width_mbs = 0, height_map_units = 0;
-  bool frame_mbs_only = true, scaling_matrix = false, delta_pic_order_always_zero = false;
+  bool frame_mbs_only = true, delta_pic_order_always_zero = false;
   int crop[4] = {0, 0, 0, 0};
+  ScalingLists scaling;
 };
 struct Pps {
+  int id = 0, sps_id = 0;
   bool cabac = false, bottom_field_pic_order = false, deblocking_control = false, constrained_intra = false;
-  bool redundant_pic_cnt = false, transform8x8 = false, scaling_matrix = false;
+  bool redundant_pic_cnt = false, transform8x8 = false;
   int num_slice_groups = 1, pic_init_qp = 26, chroma_qp_offset = 0, second_chroma_qp_offset = 0;
+  ScalingLists scaling;
 };
+// What the reconstruction library accepts (dryv_recon_check_params): the parser refuses anything larger, so that no later
+// size computation can overflow and the caller's buffers, sized from the parameters it is given, are the ones written.
+constexpr int MAX_WIDTH_MBS = 1024, MAX_HEIGHT_MBS = 65535;
 
 inline Sps parse_sps(const std::vector<uint8_t>& rbsp) {  // 7.3.2.1.1 (atom/avcc/sps.rs:42-121)
   BitReader r{rbsp.data(), rbsp.size(), 0};
@@ -137,45 +206,71 @@ inline Sps parse_sps(const std::vector<uint8_t>& rbsp) {  // 7.3.2.1.1 (atom/avc
   s.profile_idc = (int)r.bits(8);
   r.bits(8);
   s.level_idc = (int)r.bits(8);
-  r.ue();
+  const unsigned sid = r.ue();
+  if (sid > 31) fail("SPS: seq_parameter_set_id out of range");
+  s.id = (int)sid;
   const int p = s.profile_idc;
   if (p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 || p == 128 || p == 138 ||
       p == 139 || p == 134 || p == 135) {
-    s.chroma_format_idc = (int)r.ue();
+    const unsigned cfi = r.ue();
+    if (cfi > 3) fail("SPS: chroma_format_idc out of range");
+    s.chroma_format_idc = (int)cfi;
     if (s.chroma_format_idc == 3) r.bit();
-    s.bit_depth_luma = 8 + (int)r.ue();
-    s.bit_depth_chroma = 8 + (int)r.ue();
+    const unsigned bl = r.ue(), bc = r.ue();
+    if (bl > 6 || bc > 6) fail("SPS: bit depth out of range");
+    s.bit_depth_luma = 8 + (int)bl;
+    s.bit_depth_chroma = 8 + (int)bc;
     r.bit();  // qpprime_y_zero_transform_bypass_flag
-    s.scaling_matrix = r.bit() != 0;
-    if (s.scaling_matrix) fail("unsupported: sequence scaling matrix present");
+    if (r.bit()) s.scaling = read_scaling_matrix(r, s.chroma_format_idc != 3 ? 8 : 12);  // seq_scaling_matrix_present_flag
   }
-  s.log2_max_frame_num = 4 + (int)r.ue();
-  s.poc_type = (int)r.ue();
-  if (s.poc_type == 0) s.log2_max_poc_lsb = 4 + (int)r.ue();
-  else if (s.poc_type == 1) {
+  const unsigned lfn = r.ue();
+  if (lfn > 12) fail("SPS: log2_max_frame_num out of range");
+  s.log2_max_frame_num = 4 + (int)lfn;
+  const unsigned pt = r.ue();
+  if (pt > 2) fail("SPS: pic_order_cnt_type out of range");
+  s.poc_type = (int)pt;
+  if (s.poc_type == 0) {
+    const unsigned lp = r.ue();
+    if (lp > 12) fail("SPS: log2_max_pic_order_cnt_lsb out of range");
+    s.log2_max_poc_lsb = 4 + (int)lp;
+  } else if (s.poc_type == 1) {
     s.delta_pic_order_always_zero = r.bit() != 0;
     r.se();
     r.se();
     const unsigned k = r.ue();
+    if (k > 255) fail("SPS: num_ref_frames_in_pic_order_cnt_cycle out of range");
     for (unsigned i = 0; i < k; i++) r.se();
   }
   r.ue();   // max_num_ref_frames
   r.bit();  // gaps_in_frame_num_value_allowed_flag
-  s.width_mbs = 1 + (int)r.ue();
-  s.height_map_units = 1 + (int)r.ue();
+  // picture size: bounded here, by what the reconstruction library takes, before anything is sized from it
+  const unsigned wm1 = r.ue(), hm1 = r.ue();
+  if (wm1 >= (unsigned)MAX_WIDTH_MBS || hm1 >= (unsigned)MAX_HEIGHT_MBS) fail("SPS: picture larger than 1024 x 65535 macroblocks");
+  s.width_mbs = 1 + (int)wm1;
+  s.height_map_units = 1 + (int)hm1;
   s.frame_mbs_only = r.bit() != 0;
   if (!s.frame_mbs_only) r.bit();
   r.bit();  // direct_8x8_inference_flag
-  if (r.bit())
-    for (int k = 0; k < 4; k++) s.crop[k] = (int)r.ue();
+  if (r.bit()) {
+    unsigned c[4];
+    for (int k = 0; k < 4; k++) c[k] = r.ue();
+    // in units of two luma samples (4:2:0 frame pictures): what is left must be a picture
+    if (c[0] > 8u * MAX_WIDTH_MBS || c[1] > 8u * MAX_WIDTH_MBS || c[0] + c[1] >= 8u * (unsigned)s.width_mbs ||
+        c[2] > 8u * MAX_HEIGHT_MBS || c[3] > 8u * MAX_HEIGHT_MBS || c[2] + c[3] >= 8u * (unsigned)s.height_map_units)
+      fail("SPS: frame cropping rectangle outside the picture");
+    for (int k = 0; k < 4; k++) s.crop[k] = (int)c[k];
+  }
   return s;  // (VUI not needed)
 }
 
-inline Pps parse_pps(const std::vector<uint8_t>& rbsp) {  // 7.3.2.2 (atom/avcc/pps.rs:30-58)
+// chroma_format_idc: of the sequence parameter set the PPS refers to (it decides how many 8x8 lists a matrix carries)
+inline Pps parse_pps(const std::vector<uint8_t>& rbsp, int chroma_format_idc = 1) {  // 7.3.2.2 (atom/avcc/pps.rs:30-58)
   BitReader r{rbsp.data(), rbsp.size(), 0};
   Pps p;
-  r.ue();
-  r.ue();
+  const unsigned pid = r.ue(), sid = r.ue();
+  if (pid > 255 || sid > 31) fail("PPS: parameter set id out of range");
+  p.id = (int)pid;
+  p.sps_id = (int)sid;
   p.cabac = r.bit() != 0;
   p.bottom_field_pic_order = r.bit() != 0;
   p.num_slice_groups = 1 + (int)r.ue();
@@ -185,8 +280,10 @@ inline Pps parse_pps(const std::vector<uint8_t>& rbsp) {  // 7.3.2.2 (atom/avcc/
   r.bit();    // weighted_pred_flag
   r.bits(2);  // weighted_bipred_idc
   p.pic_init_qp = 26 + r.se();
+  if (p.pic_init_qp < 0 || p.pic_init_qp > 51) fail("PPS: pic_init_qp out of range");
   r.se();
   p.chroma_qp_offset = r.se();
+  if (p.chroma_qp_offset < -12 || p.chroma_qp_offset > 12) fail("PPS: chroma_qp_index_offset out of range");
   p.second_chroma_qp_offset = p.chroma_qp_offset;  // transform.rs:198-203: falls back to the first offset
   p.deblocking_control = r.bit() != 0;
   p.constrained_intra = r.bit() != 0;
@@ -200,9 +297,10 @@ inline Pps parse_pps(const std::vector<uint8_t>& rbsp) {  // 7.3.2.2 (atom/avcc/
     const size_t end_bit = 8 * last - tz - 1;  // position of the rbsp_stop_one_bit
     if (r.pos < end_bit) {
       p.transform8x8 = r.bit() != 0;
-      p.scaling_matrix = r.bit() != 0;
-      if (p.scaling_matrix) fail("unsupported: picture scaling matrix present");
+      if (r.bit())  // pic_scaling_matrix_present_flag (pps.rs:77-82)
+        p.scaling = read_scaling_matrix(r, 6 + (chroma_format_idc != 3 ? 2 : 6) * (p.transform8x8 ? 1 : 0));
       p.second_chroma_qp_offset = r.se();
+      if (p.second_chroma_qp_offset < -12 || p.second_chroma_qp_offset > 12) fail("PPS: second_chroma_qp_index_offset out of range");
     }
   }
   return p;
@@ -218,7 +316,7 @@ inline SliceHeader parse_slice_header(BitReader& r, const Sps& s, const Pps& p, 
   h.first_mb = (int)r.ue();
   h.slice_type = (int)r.ue();
   if (h.slice_type % 5 != 2) fail("unsupported: not an I slice");
-  r.ue();  // pic_parameter_set_id
+  if (r.ue() != (unsigned)p.id) fail("slice header: not the picture parameter set it was paired with");
   h.frame_num = (int)r.bits(s.log2_max_frame_num);
   if (!s.frame_mbs_only && r.bit()) fail("unsupported: field picture");
   if (nal_unit_type == 5) h.idr_pic_id = (int)r.ue();
@@ -245,6 +343,7 @@ inline SliceHeader parse_slice_header(BitReader& r, const Sps& s, const Pps& p, 
     }
   }
   h.slice_qp = p.pic_init_qp + r.se();
+  if (h.slice_qp < 0 || h.slice_qp > 51) fail("slice header: slice_qp out of range");
   if (p.deblocking_control) {
     h.disable_deblocking_filter_idc = (int)r.ue();
     if (h.disable_deblocking_filter_idc != 1) {
@@ -798,7 +897,11 @@ struct MbLayer {
   }
 };
 
-inline void set_flat_params(dryv_frame_params& fp, int W, int H, const Pps& p) {
+// The frame parameters of a picture coded under (s, p). Scaling lists: the SPS's matrix if it has one, else the PPS's,
+// else flat 16 (slice/header.rs:317-332 -- the reference's order, see ScalingLists).
+inline void set_params(dryv_frame_params& fp, const Sps& s, const Pps& p) {
+  const int W = s.width_mbs, H = s.height_map_units;
+  if (W < 1 || W > MAX_WIDTH_MBS || H < 1 || H > MAX_HEIGHT_MBS) fail("picture size out of range");
   memset(&fp, 0, sizeof fp);
   fp.pic_width_in_mbs = (uint16_t)W;
   fp.pic_height_in_mbs = (uint16_t)H;
@@ -810,6 +913,11 @@ inline void set_flat_params(dryv_frame_params& fp, int W, int H, const Pps& p) {
   fp.transform_8x8_mode_flag = p.transform8x8;
   memset(fp.scaling_list4x4, 16, sizeof fp.scaling_list4x4);  // flat (header.rs:330)
   memset(fp.scaling_list8x8, 16, sizeof fp.scaling_list8x8);
+  const ScalingLists* L = s.scaling.present ? &s.scaling : p.scaling.present ? &p.scaling : nullptr;
+  if (L) {
+    memcpy(fp.scaling_list4x4, L->l4, sizeof fp.scaling_list4x4);
+    for (int k = 0; k < L->n8 && k < 6; k++) memcpy(fp.scaling_list8x8[k], L->l8[k], 64);
+  }
 }
 
 // Parses one coded slice NAL unit (header byte included) given the active parameter sets.
@@ -830,7 +938,7 @@ inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, 
     if (r.bit() != 1) fail("cabac_alignment_one_bit is 0");  // cabac/mod.rs:71-73
   ParsedFrame F;
   const int W = s.width_mbs, H = s.height_map_units;
-  set_flat_params(F.fp, W, H, p);
+  set_params(F.fp, s, p);
   if (!mbs_out || !co_out) {
     F.mbs.resize((size_t)W * H);
     F.coeffs.assign((size_t)W * H * 384, 0);
@@ -865,25 +973,50 @@ inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, 
 }
 
 // ---- containers ------------------------------------------------------------------------------------------------------------
+// Parameter sets are kept by id, every version of them (a stream may send a set again with other content: 7.4.1.2.1);
+// a coded slice is paired, when it is seen, with the sets that are active for it at that point of the stream.
 struct Stream {
-  Sps sps;
-  Pps pps;
-  bool have_sps = false, have_pps = false;
-  struct Nal { const uint8_t* p; size_t n; };
+  std::vector<Sps> spsAll;   // append-only
+  std::vector<Pps> ppsAll;
+  int spsById[32], ppsById[256];  // index of the latest version, -1 = none
+  struct Nal { const uint8_t* p; size_t n; int sps, pps; };
   std::vector<Nal> slices;  // coded slice NAL units (with header byte) inside the caller's buffer, in decoding order
+  Stream() {
+    for (int& v : spsById) v = -1;
+    for (int& v : ppsById) v = -1;
+  }
+  const Sps& sps_of(const Nal& nal) const { return spsAll[(size_t)nal.sps]; }
+  const Pps& pps_of(const Nal& nal) const { return ppsAll[(size_t)nal.pps]; }
 };
 
 inline void take_nal(Stream& S, const uint8_t* p, size_t n) {
   if (n < 1) return;
   const int type = p[0] & 31;
-  if (type == 7 && !S.have_sps) {
-    S.sps = parse_sps(unescape(p + 1, n - 1));
-    S.have_sps = true;
-  } else if (type == 8 && !S.have_pps) {
-    S.pps = parse_pps(unescape(p + 1, n - 1));
-    S.have_pps = true;
+  if (type == 7) {
+    S.spsAll.push_back(parse_sps(unescape(p + 1, n - 1)));
+    S.spsById[S.spsAll.back().id] = (int)S.spsAll.size() - 1;
+  } else if (type == 8) {
+    // (the PPS's matrix size depends on the chroma format of the SPS it names; an unknown one counts as 4:2:0 and the
+    // slice is refused later for want of its SPS)
+    const std::vector<uint8_t> rbsp = unescape(p + 1, n - 1);
+    BitReader peek{rbsp.data(), rbsp.size(), 0};
+    peek.ue();
+    const unsigned sid = peek.ue();
+    const int si = sid < 32 ? S.spsById[sid] : -1;
+    S.ppsAll.push_back(parse_pps(rbsp, si >= 0 ? S.spsAll[(size_t)si].chroma_format_idc : 1));
+    S.ppsById[S.ppsAll.back().id] = (int)S.ppsAll.size() - 1;
   } else if (type == 5 || type == 1) {
-    S.slices.push_back(Stream::Nal{p, n});
+    // first_mb_in_slice, slice_type, pic_parameter_set_id (7.3.3): the first three ue(v) of the header
+    const std::vector<uint8_t> rbsp = unescape(p + 1, std::min<size_t>(n - 1, 24));
+    BitReader r{rbsp.data(), rbsp.size(), 0};
+    r.ue();
+    r.ue();
+    const unsigned pid = r.ue();
+    const int pi = pid < 256 ? S.ppsById[pid] : -1;
+    if (pi < 0) fail("coded slice refers to a picture parameter set that was not sent");
+    const int si = S.spsById[S.ppsAll[(size_t)pi].sps_id];
+    if (si < 0) fail("picture parameter set refers to a sequence parameter set that was not sent");
+    S.slices.push_back(Stream::Nal{p, n, si, pi});
   }
 }
 
@@ -900,7 +1033,7 @@ inline bool find_atom(const uint8_t* p, size_t n, const char* name, const uint8_
       sz = be64(p + off + 8);
       hdr = 16;
     } else if (sz == 0) sz = n - off;
-    if (sz < hdr || off + sz > n) return false;
+    if (sz < hdr || sz > n - off) return false;   // (off <= n - 8 here: no sum that could wrap)
     if (memcmp(p + off + 4, name, 4) == 0) {
       out = p + off + hdr;
       outn = (size_t)sz - hdr;
@@ -937,21 +1070,20 @@ inline Stream demux_mp4(const uint8_t* f, size_t n, size_t max_samples) {
   const int lenSize = (q[4] & 3) + 1;
   size_t o = 5;
   const int nsps = q[o++] & 31;
-  for (int k = 0; k < nsps; k++) {
-    const size_t l = ((size_t)q[o] << 8) | q[o + 1];
-    o += 2;
-    if (o + l > nq) fail("mp4: avcC truncated");
-    take_nal(S, q + o, l);
-    o += l;
-  }
+  auto take_sets = [&](int count) {
+    for (int k = 0; k < count; k++) {
+      if (nq - o < 2) fail("mp4: avcC truncated");
+      const size_t l = ((size_t)q[o] << 8) | q[o + 1];
+      o += 2;
+      if (l > nq - o) fail("mp4: avcC truncated");
+      take_nal(S, q + o, l);
+      o += l;
+    }
+  };
+  take_sets(nsps);
+  if (o >= nq) fail("mp4: avcC truncated");
   const int npps = q[o++];
-  for (int k = 0; k < npps; k++) {
-    const size_t l = ((size_t)q[o] << 8) | q[o + 1];
-    o += 2;
-    if (o + l > nq) fail("mp4: avcC truncated");
-    take_nal(S, q + o, l);
-    o += l;
-  }
+  take_sets(npps);
   const uint8_t *stsz, *stco, *stsc;
   size_t nstsz, nstco, nstsc;
   if (!find_atom(stbl, nstbl, "stsz", stsz, nstsz) || nstsz < 12) fail("mp4: no stsz");
@@ -977,14 +1109,14 @@ inline Stream demux_mp4(const uint8_t* f, size_t n, size_t max_samples) {
     uint64_t off = co64 ? be64(stco + 8 + 8 * (size_t)c) : be32(stco + 8 + 4 * (size_t)c);
     for (uint32_t k = 0; k < perChunk && sample < nSamples && sample < max_samples; k++, sample++) {
       const uint32_t size = fixedSize ? fixedSize : be32(stsz + 12 + 4 * sample);
-      if (off + size > n) fail("mp4: sample outside the file");
+      if (size > n || off > n - size) fail("mp4: sample outside the file");   // (no sum that could wrap: off is 64 bits from co64)
       const uint8_t* sp = f + off;
       size_t so = 0;
-      while (so + lenSize <= size) {
+      while (size - so >= (size_t)lenSize) {
         size_t l = 0;
         for (int q2 = 0; q2 < lenSize; q2++) l = (l << 8) | sp[so + q2];
         so += lenSize;
-        if (so + l > size) fail("mp4: NAL unit outside the sample");
+        if (l > size - so) fail("mp4: NAL unit outside the sample");
         take_nal(S, sp + so, l);
         so += l;
       }
@@ -1022,9 +1154,8 @@ inline Stream demux_annexb(const uint8_t* f, size_t n) {
 inline ParsedFrame parse_first_islice(const uint8_t* f, size_t n) {
   const bool mp4 = n >= 12 && memcmp(f + 4, "ftyp", 4) == 0;
   Stream S = mp4 ? demux_mp4(f, n, 1) : demux_annexb(f, n);
-  if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
-  if (S.slices.empty()) fail("no coded slice");
-  return parse_islice_nal(S.slices[0].p, S.slices[0].n, S.sps, S.pps);
+  if (S.slices.empty()) fail(S.spsAll.empty() || S.ppsAll.empty() ? "no SPS / PPS" : "no coded slice");
+  return parse_islice_nal(S.slices[0].p, S.slices[0].n, S.sps_of(S.slices[0]), S.pps_of(S.slices[0]));
 }
 
 // Whether a coded slice NAL unit starts a picture that consists of one I slice (what this parser decodes).
@@ -1053,7 +1184,7 @@ inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, si
                                                   int16_t* co_out = nullptr, size_t capacity = 0) {
   const bool mp4 = n >= 12 && memcmp(f + 4, "ftyp", 4) == 0;
   Stream S = mp4 ? demux_mp4(f, n, (size_t)-1) : demux_annexb(f, n);
-  if (!S.have_sps || !S.have_pps) fail("no SPS / PPS");
+  if (S.spsAll.empty() || S.ppsAll.empty()) fail("no SPS / PPS");
   std::vector<Stream::Nal> todo;
   size_t skip = 0;
   for (const Stream::Nal& nal : S.slices) {
@@ -1066,10 +1197,16 @@ inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, si
   }
   if (skipped) *skipped = skip;
   if (todo.empty()) fail("no intra picture");
-  const size_t perPic = (size_t)S.sps.width_mbs * S.sps.height_map_units;
+  // one batch buffer = pictures of one size: every picture must have the first one's (bounded by parse_sps, so none of
+  // the products below can overflow), and the caller's capacity is in pictures of that size
+  const size_t perPic = (size_t)S.sps_of(todo[0]).width_mbs * (size_t)S.sps_of(todo[0]).height_map_units;
+  for (const Stream::Nal& nal : todo)
+    if ((size_t)S.sps_of(nal).width_mbs * (size_t)S.sps_of(nal).height_map_units != perPic ||
+        S.sps_of(nal).width_mbs != S.sps_of(todo[0]).width_mbs)
+      fail("pictures of different sizes in one stream");
   if (mbs_out && co_out && todo.size() > capacity) fail("batch buffer too small");
   auto parse_one = [&](size_t k) {
-    return parse_islice_nal(todo[k].p, todo[k].n, S.sps, S.pps, mbs_out && co_out ? mbs_out + k * perPic : nullptr,
+    return parse_islice_nal(todo[k].p, todo[k].n, S.sps_of(todo[k]), S.pps_of(todo[k]), mbs_out && co_out ? mbs_out + k * perPic : nullptr,
                             mbs_out && co_out ? co_out + k * perPic * 384 : nullptr);
   };
   std::vector<ParsedFrame> out(todo.size());
@@ -1089,6 +1226,12 @@ inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, si
       } catch (const Error& e) {
         errs[t] = e.what.empty() ? "parse error" : e.what;
         next = todo.size();
+      } catch (const std::exception& e) {  // (bad_alloc and friends must not leave a std::thread)
+        errs[t] = std::string("parse: ") + e.what();
+        next = todo.size();
+      } catch (...) {
+        errs[t] = "parse: unknown exception";
+        next = todo.size();
       }
     });
   for (std::thread& th : pool) th.join();
@@ -1103,11 +1246,16 @@ inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, si
 inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const dryv_mb_desc* mbs, const int16_t* coeffs,
                                               int slice_qp = 26, const int* crop = nullptr, int n_pictures = 1) {
   const int W = fp.pic_width_in_mbs, H = fp.pic_height_in_mbs;
+  if (W < 1 || W > MAX_WIDTH_MBS || H < 1 || n_pictures < 1) fail("encoder: picture size out of range");
+  // Non-flat lists travel as a sequence scaling matrix with every list sent explicitly (a list left out would come back
+  // as the Default_* table: ScalingLists above). A 4:2:0 stream carries two 8x8 lists (Intra Y, Inter Y).
+  bool flat = true;
   for (int l = 0; l < 6; l++) {
-    for (int k = 0; k < 16; k++)
-      if (fp.scaling_list4x4[l][k] != 16) fail("encoder: flat scaling lists only");
-    for (int k = 0; k < 64; k++)
-      if (fp.scaling_list8x8[l][k] != 16) fail("encoder: flat scaling lists only");
+    for (int k = 0; k < 16; k++) flat = flat && fp.scaling_list4x4[l][k] == 16;
+    for (int k = 0; k < 64; k++) {
+      flat = flat && fp.scaling_list8x8[l][k] == 16;
+      if (l >= 2 && fp.scaling_list8x8[l][k] != 16) fail("encoder: a 4:2:0 stream carries only the two luma 8x8 scaling lists");
+    }
   }
   std::vector<uint8_t> out;
   {
@@ -1120,7 +1268,13 @@ inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const
     w.ue(0);
     w.ue(0);
     w.bit(0);
-    w.bit(0);  // seq_scaling_matrix_present_flag
+    w.bit(flat ? 0 : 1);  // seq_scaling_matrix_present_flag
+    if (!flat)
+      for (int l = 0; l < 8; l++) {
+        w.bit(1);  // seq_scaling_list_present_flag
+        if (l < 6) write_scaling_list(w, fp.scaling_list4x4[l], 16);
+        else write_scaling_list(w, fp.scaling_list8x8[l - 6], 64);
+      }
     w.ue(0);   // log2_max_frame_num_minus4
     w.ue(2);   // pic_order_cnt_type
     w.ue(1);   // max_num_ref_frames
@@ -1203,6 +1357,12 @@ inline std::vector<uint8_t> encode_idr_annexb(const dryv_frame_params& fp, const
           for (int pic = next++; pic < n_pictures; pic = next++) encode_picture(pic);
         } catch (const Error& e) {
           errs[t] = e.what.empty() ? "encode error" : e.what;
+          next = n_pictures;
+        } catch (const std::exception& e) {
+          errs[t] = std::string("encode: ") + e.what();
+          next = n_pictures;
+        } catch (...) {
+          errs[t] = "encode: unknown exception";
           next = n_pictures;
         }
       });

@@ -168,3 +168,127 @@ def test_parse_into_batch_buffers_in_parallel():
     assert n2 == frames and info["tails_ok"] == 1 and np.array_equal(c_out, ref[3]) and np.array_equal(m_out, ref[2])
     with pytest.raises(h264.H264Error):                              # too small a buffer is refused, not overrun
         h264.parse_all_islices_into(stream, m_out[:3 * per], c_out[:3 * per], threads=2)
+
+
+# ---- hardening (round 3): sizes are bounded where they are parsed, nothing crosses the C boundary by exception ---------
+class _Bits:
+    """A minimal RBSP writer for hand-made parameter sets."""
+    def __init__(self):
+        self.b = []
+
+    def u(self, v, n):
+        self.b += [(v >> i) & 1 for i in range(n - 1, -1, -1)]
+
+    def ue(self, v):
+        x = int(v) + 1
+        n = x.bit_length() - 1
+        self.u(0, n)
+        self.u(x, n + 1)
+
+    def se(self, v):
+        self.ue(2 * v - 1 if v > 0 else -2 * v)
+
+    def nal(self, header):
+        bits = self.b + [1]
+        bits += [0] * (-len(bits) % 8)
+        raw = bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+        out, zeros = bytearray(b"\x00\x00\x00\x01" + bytes([header])), 0
+        for c in raw:   # emulation prevention
+            if zeros >= 2 and c <= 3:
+                out.append(3)
+                zeros = 0
+            out.append(c)
+            zeros = zeros + 1 if c == 0 else 0
+        return bytes(out)
+
+
+def _sps(width_mbs_minus1, height_mbs_minus1, matrix=None):
+    """High-profile SPS; matrix: None or a list of 8 entries, each None (list not present) or a list of values."""
+    w = _Bits()
+    w.u(100, 8); w.u(0, 8); w.u(40, 8); w.ue(0)
+    w.ue(1); w.ue(0); w.ue(0); w.u(0, 1)
+    w.u(1 if matrix else 0, 1)
+    if matrix:
+        for lst in matrix:
+            w.u(0 if lst is None else 1, 1)
+            last = 8
+            for v in (lst or []):
+                v = int(v)
+                d = v - last
+                d = d - 256 if d > 127 else d + 256 if d < -128 else d
+                w.se(d)
+                last = v
+    w.ue(0); w.ue(2); w.ue(1); w.u(0, 1)
+    w.ue(width_mbs_minus1); w.ue(height_mbs_minus1)
+    w.u(1, 1); w.u(1, 1); w.u(0, 1); w.u(0, 1)
+    return w.nal(0x67)
+
+
+def _replace_sps(stream, sps):
+    """The Annex-B stream with its first NAL unit (the encoder writes the SPS first) replaced."""
+    nxt = stream.index(b"\x00\x00\x00\x01", 4)
+    return sps + stream[nxt:]
+
+
+def test_oversized_picture_in_sps_is_refused_not_truncated():
+    """pic_width_in_mbs_minus1 = 65536 used to be truncated to uint16 in the parameters the caller sizes
+    its buffers from (1x1) while the parse loop kept the full width and wrote past them."""
+    fp = abi.make_frame_params(1, 1)
+    mbs, co = synth.generate(fp, synth.config(), 5, 0, 1)
+    good = h264.encode_stream(fp, 1, mbs, co, slice_qp=int(mbs["qp"][0]))
+    assert h264.stream_params(good)[0].pic_width_in_mbs == 1
+    for wm1, hm1 in ((65536, 0), (0, 65536), (1024, 0), (70000, 70000), (2 ** 31, 3)):
+        bad = _replace_sps(good, _sps(wm1, hm1))
+        with pytest.raises(h264.H264Error, match="larger than"):
+            h264.stream_params(bad)
+        m1, c1 = np.zeros(1, dtype=abi.MB_DESC_DTYPE), np.zeros(384, dtype=np.int16)
+        with pytest.raises(h264.H264Error):
+            h264.parse_all_islices_into(bad, m1, c1)
+        with pytest.raises(h264.H264Error):
+            h264.parse_first_islice(bad)
+    # the largest picture the library takes is still parsed as such (the slice then fails: it is a 1-macroblock slice)
+    big = _replace_sps(good, _sps(1023, 9))
+    assert (h264.stream_params(big)[0].pic_width_in_mbs, h264.stream_params(big)[0].pic_height_in_mbs) == (1024, 10)
+
+
+def test_scaling_matrix_round_trip_and_reference_fallback():
+    """Non-flat lists travel in the SPS and come back entry for entry; a list that is not present becomes the Default_*
+    table -- the reference's rule (atom/avcc/sps.rs:206-249), not the standard's fall-back rule A."""
+    fp = abi.make_frame_params(5, 4, transform_8x8=True)
+    rng = np.random.default_rng(11)
+    l4 = rng.integers(1, 256, size=(6, 16), dtype=np.uint8)
+    l8 = np.full((6, 64), 16, dtype=np.uint8)
+    l8[:2] = rng.integers(1, 256, size=(2, 64), dtype=np.uint8)
+    np.ctypeslib.as_array(fp.scaling_list4x4)[:] = l4
+    np.ctypeslib.as_array(fp.scaling_list8x8)[:] = l8
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3), 13, 0, 2)
+    stream = h264.encode_stream(fp, 2, mbs, co, slice_qp=int(mbs["qp"][0]))
+    fp2, n, m2, c2, info = h264.parse_all_islices(stream)
+    assert n == 2 and bytes(fp2) == bytes(fp) and np.array_equal(m2, mbs) and np.array_equal(c2, co)
+    # lists 1 and 7 left out, list 3 switched to its default by a leading zero
+    matrix = [list(l4[0]), None, list(l4[2]), [0], list(l4[4]), list(l4[5]), list(l8[0]), None]
+    # ([0] codes delta_scale = -8 for entry 0: nextScale == 0 -> useDefaultScalingMatrixFlag)
+    s2 = _replace_sps(stream, _sps(4, 3, matrix))
+    fp3 = h264.stream_params(s2)[0]
+    got4, got8 = np.ctypeslib.as_array(fp3.scaling_list4x4), np.ctypeslib.as_array(fp3.scaling_list8x8)
+    d4i = [6, 13, 13, 20, 20, 20, 28, 28, 28, 28, 32, 32, 32, 37, 37, 42]
+    d4p = [10, 14, 14, 20, 20, 20, 24, 24, 24, 24, 27, 27, 27, 30, 30, 34]
+    assert list(got4[0]) == list(l4[0]) and list(got4[1]) == d4i and list(got4[3]) == d4p and list(got4[5]) == list(l4[5])
+    assert list(got8[0]) == list(l8[0]) and got8[1][0] == 9 and got8[1][63] == 35 and (got8[2:] == 16).all()
+
+
+def test_parser_survives_mutated_streams_under_sanitizers(tmp_path):
+    """A malformed-input fuzz of the host parser's source built with -fsanitize=address,undefined (CPU build only)."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = tmp_path / "h264_fuzz"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-o", str(exe), os.path.join(here, "fuzz", "h264_fuzz.cpp")], check=True)
+    fp = abi.make_frame_params(6, 4, transform_8x8=True)
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.4, i8x8=0.3), 17, 0, 3)
+    annexb = tmp_path / "s.h264"
+    annexb.write_bytes(h264.encode_stream(fp, 3, mbs, co, slice_qp=int(mbs["qp"][0])))
+    for seedfile, iters in ((FIXTURE, 250), (str(annexb), 400)):
+        r = subprocess.run([str(exe), seedfile, str(iters), "12345"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+        assert "rejected" in r.stdout
