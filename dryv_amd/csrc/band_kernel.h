@@ -101,8 +101,8 @@ constexpr int S_RINGC = S_STC + 64 * CW;             // [4][4][16]  bottom chrom
 constexpr int RINGC_ROW = 64, RINGC_ENT = 16;
 constexpr int S_LEFTC = S_RINGC + 256;            // u8 [4][2][8]
 // FRONT
-constexpr int S_RINGM = S_LEFTC + 64;             // u32 [4][4]  bottom-row modes of the row above
-constexpr int S_BYTES = (S_RINGM + 64 + 63) & ~63;
+constexpr int S_CARRYM = S_LEFTC + 64;            // u32 [4]     mode pre-pass: right-column modes of the macroblock left of the batch, per row
+constexpr int S_BYTES = (S_CARRYM + 64 + 63) & ~63;
 // builds that serve the 8x8 transform (HAS_I8) append, per team:
 constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order
 constexpr int S_G8 = S_C8 + 2048;      // T   [4][2 blk8][8][8]  FRONT: row-pass output of the two blocks of a pass (T up to 8 bytes)
@@ -110,7 +110,7 @@ constexpr int S_E8 = S_G8 + 4096;      // [4][128]  BACK: the filtered edge of t
                                        //           then E1 as bytes (L7..L0, TL at 100..108, T0..T15 at 112..127)
 constexpr int S_BYTES_I8 = S_E8 + 512;
 constexpr int team_bytes(bool hasI8) { return hasI8 ? S_BYTES_I8 : S_BYTES; }
-static_assert(S_RINGM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
+static_assert(S_CARRYM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
 // the luma tile of macroblock x of row g
@@ -192,8 +192,8 @@ struct Args {
   unsigned* status;
   unsigned* progY;      // [frame][band]: macroblocks of the band's last row whose bottom luma line is visible
   unsigned* progC;      // [frame][band]: the same for its bottom chroma lines
-  unsigned* progM;      // [frame][band]: the same for its bottom-row modes
-  unsigned* rowModes;   // [mb]: bottom-row Intra4x4/8x8 modes (only rows that end a band are written)
+  unsigned* progM;      // [frame][band]: W once the band's mode records (below) are visible
+  unsigned* rowModes;   // [mb][8]: the mode record of every macroblock (MREC_*), written by the band's mode pre-pass
   unsigned* taskCounter;
   unsigned long long* profile;  // DRYV_BAND_PROFILE builds only
   int waveBase;                 // (global index of the workgroup's first wave, for the same)
@@ -667,6 +667,163 @@ WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned known
 }
 
 // ==================================================================================================================
+// Prediction modes of a whole band, derived before its first step (8.3.1.1 / 8.3.2.1; pred4x4.rs:363-427,
+// pred8x8.rs:698-764). Nothing in the derivation depends on a pixel, only on the records -- so it does not have to ride
+// the 2:1 diagonal, where it cost seven DPP sweeps over the block grid per step (a fifth of FRONT's instructions).
+//   * ONE LANE PER MACROBLOCK, 64 consecutive macroblocks of a row per pass. The lane walks its sixteen grid positions
+//     in raster order with the modes in registers: neighbour A of a position is the register one to the left, B the
+//     one above; only column 0 reaches into the macroblock to the left (the lane to the left: one DPP wave shift of
+//     the packed right column) and row 0 into the macroblock above (the same lane, one row earlier: a register).
+//   * The dependence on the lane to the left is resolved by relaxation: every lane starts from "the left macroblock's
+//     right column is all DC", and the pass is repeated with the right columns the previous pass produced until no lane's
+//     right column changes (then every lane has seen its final inputs). A change only travels on when it flips a
+//     comparison, so two or three passes are the rule; the bound is one pass per lane.
+//   * Out: one 32-byte mode record per macroblock in global memory (workspace), in exactly the form the steps consume:
+//       bytes 0..23  the Intra4x4 chain's table rows x 8, [block half][chain round] (= S_MSEQ's layout; rows 9..11 =
+//                    zero prediction of quirk Q4 / modes 3, 7 without a top-right block); an Intra8x8 macroblock:
+//                    bytes 0..3 = its four modes x 8
+//       word 6       chain rounds of the macroblock that have a DC-predicted block (bit t)
+//       word 7       the raw modes of its bottom grid row (DC for any other macroblock kind): neighbour B of the row below
+//     written through (sc1) and published per band by one progress word (progM = W) for the band below; the band's own
+//     steps load them back one step ahead, like the records.
+constexpr int MREC_WORDS = 8;
+template <bool HAS_I8>
+WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsigned task, const int ts, const uint8_t* mbsF,
+                   unsigned* recF, const unsigned* upProgM, unsigned* myProgM) {
+  const int lane = wv::lane_id();
+  const int W = P.W;
+  if (G.hasAbove) poll_progress(upProgM, upProgM, 0u, (unsigned)W, (unsigned)W, A.status, task, -1, lane);
+  if (lane < 4) wv::lds_st32(ts + S_CARRYM + 4 * lane, 0x02020202u);
+  wv::wave_sync();
+#pragma clang loop unroll(disable)
+  for (int x0 = 0; x0 < W; x0 += 64) {
+    const int x = x0 + lane;
+    const bool valid = x < W;
+    const int xc = min(x, W - 1);
+    const bool xIs0 = x == 0, xLast = x + 1 >= W;
+    unsigned bottom = 0x02020202u;  // raw modes of the bottom grid row of the macroblock above (same lane)
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < G.nR; g++) {
+      const int r = G.r0 + g;
+      const bool rowTop = r > 0;  // (wave-uniform) macroblock B exists
+      const unsigned mb = (unsigned)(r * W + xc);
+      const u32x4 d = wv::ld_u128_a2(mbsF + 16u * mb);
+      unsigned topM = bottom;
+      if (g == 0 && rowTop) topM = wv::ld_sc1(recF + (size_t)MREC_WORDS * (mb - (unsigned)W) + 7);
+      const unsigned carry = wv::lds_u32(ts + S_CARRYM + 4 * g);
+      // the record checks of the step (an unsupported record reconstructs as zero and counts as DC for its neighbours)
+      int kind = (int)(d.x & 0xffu);
+      if (kind > 2 || (!HAS_I8 && kind == 1) || (d.x >> 24) > 51u || ((d.x >> 8) & 0xffu) > 3u || ((d.x >> 16) & 0xffu) > 3u) kind = 3;
+      const bool isI4 = kind == 0, is8 = HAS_I8 && kind == 1;
+      // rem fields as nibbles in blkIdx order, bit 3 of a nibble set where prev_intra*_pred_mode_flag is: such a block
+      // takes the predicted mode, and its "rem" of 8..15 is not below any mode
+      const unsigned prevFlags = d.y & 0xffffu;
+      auto spread8 = [](unsigned p) -> unsigned {  // bit k of p -> bit 4 * k + 3
+        unsigned v = p & 0xffu;
+        v = (v | (v << 12)) & 0x000f000fu;
+        v = (v | (v << 6)) & 0x03030303u;
+        v = (v | (v << 3)) & 0x11111111u;
+        return v << 3;
+      };
+      const unsigned remLo = (wv::alignbit(d.z, d.y, 16) & 0x77777777u) | spread8(prevFlags);
+      const unsigned remHi = (wv::alignbit(d.w, d.z, 16) & 0x77777777u) | spread8(prevFlags >> 8);
+      int M[16];
+#pragma unroll
+      for (int b = 0; b < 16; b++) M[b] = 2;
+      unsigned rc = 0x02020202u;
+      for (int pass = 0; pass < 66; pass++) {
+        // the right column of the macroblock to the left as of the previous pass; lane 0: of the previous batch (final)
+        const unsigned lc = (unsigned)wv::dpp<DPP_WAVE_SHR1>((int)carry, (int)rc);
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+          const int bx = b & 3, by = b >> 2;
+          const int An = bx ? M[b - 1] : (int)((lc >> (8 * by)) & 0xffu);
+          const int Bn = by ? M[b - 4] : (int)((topM >> (8 * bx)) & 0xffu);
+          int pm = min(An, Bn);
+          if (bx == 0) pm = xIs0 ? 2 : pm;       // dcPredModePredictedFlag: no macroblock A
+          if (by == 0) pm = rowTop ? pm : 2;     // ... no macroblock B
+          const int z = zidx(bx, by);
+          int rm = (int)(((z < 8 ? remLo : remHi) >> (4 * (z & 7))) & 15u);
+          if (HAS_I8) {
+            // an 8x8 block: its top-left position derives the mode like a 4x4 block there would, from the block's own
+            // flag and rem field; the other three positions copy it
+            const int z8 = 2 * (by >> 1) + (bx >> 1);
+            if (is8) rm = (int)((remLo >> (4 * z8)) & 15u);
+          }
+          int m = rm > 7 ? pm : (rm < pm ? rm : rm + 1);
+          if (HAS_I8 && ((bx | by) & 1)) m = is8 ? M[(b & ~1) & ~4] : m;
+          M[b] = m;
+        }
+        unsigned rcN = (unsigned)M[3] | ((unsigned)M[7] << 8) | ((unsigned)M[11] << 16) | ((unsigned)M[15] << 24);
+        if (!(isI4 || is8)) rcN = 0x02020202u;
+        const bool changed = valid && rcN != rc;
+        rc = rcN;
+        if (!wv::any(changed)) break;
+      }
+      // the batch's last macroblock is the next batch's macroblock A (every lane has converged: final)
+      if (lane == 63) wv::lds_st32(ts + S_CARRYM + 4 * g, rc);
+      bottom = (isI4 || is8) ? ((unsigned)M[12] | ((unsigned)M[13] << 8) | ((unsigned)M[14] << 16) | ((unsigned)M[15] << 24)) : 0x02020202u;
+
+      // ---- the record: table rows of the chain
+      unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, dcMask = 0;
+      if (wv::any(isI4)) {
+        int T[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++) T[b] = M[b];
+        // modes 3 and 7 without a top-right block: T4..T7 := T3 (table rows 10 and 11). Inside the macroblock positions
+        // (1,1) (3,1) (3,2) (1,3) (3,3) never have one; the top row has the neighbours' (B, B, B, C)
+        auto no_tr = [](int m) -> int { return (m & 3) == 3 ? 10 + (m >> 2) : m; };
+        T[5] = no_tr(T[5]); T[7] = no_tr(T[7]); T[11] = no_tr(T[11]); T[13] = no_tr(T[13]); T[15] = no_tr(T[15]);
+        if (!rowTop) { T[0] = no_tr(T[0]); T[1] = no_tr(T[1]); T[2] = no_tr(T[2]); }
+        T[3] = (rowTop && !xLast) ? T[3] : no_tr(T[3]);
+        if (!rowTop || x0 == 0) {
+          // quirk Q4 (picture edges only): a mode whose reference samples are missing leaves the zero-initialised
+          // prediction (table row 9)
+#pragma unroll
+          for (int b = 0; b < 16; b++) {
+            const int bx = b & 3, by = b >> 2;
+            if (bx != 0 && by != 0) continue;
+            const bool topAv = by > 0 || rowTop, leftAv = bx > 0 || !xIs0;
+            const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
+            const int req = (int)((0x217771021ull >> (4 * M[b])) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
+            if ((req & ~have) != 0) T[b] = 9;
+          }
+        }
+        // x 8 (the table row's byte offset), in the order [block half][chain round]: round t = bx + 2 by; the first half
+        // is the block with the smaller by
+        auto pk = [](int a, int b2, int c, int e) -> unsigned {
+          return ((unsigned)a << 3) | ((unsigned)b2 << 11) | ((unsigned)c << 19) | ((unsigned)e << 27);
+        };
+        w0 = pk(T[0], T[1], T[2], T[3]);            // rounds 0..3: (0,0) (1,0) (2,0) (3,0)
+        w1 = pk(T[6], T[7], T[10], T[11]);          // rounds 4..7: (2,1) (3,1) (2,2) (3,2)
+        w2 = pk(T[14], T[15], 0, 0);                // rounds 8, 9: (2,3) (3,3)
+        w3 = pk(0, 0, T[4], T[5]);                  // second half, rounds 2, 3: (0,1) (1,1)
+        w4 = pk(T[8], T[9], T[12], T[13]);          // ... rounds 4..7: (0,2) (1,2) (0,3) (1,3)
+        // rounds with a DC block: bytes equal to 16 (all bytes are < 128: no carry between the bytes of the sum)
+        auto dc4 = [](unsigned w) -> unsigned { return ~((w ^ 0x10101010u) + 0x7f7f7f7fu) & 0x80808080u; };
+        auto gather = [](unsigned zz) -> unsigned {  // bits 7, 15, 23, 31 -> bits 0..3
+          unsigned q = zz >> 7;
+          q |= q >> 7;
+          return (q | (q >> 14)) & 15u;
+        };
+        dcMask = gather(dc4(w0) | dc4(w3)) | (gather(dc4(w1) | dc4(w4)) << 4) | (gather(dc4(w2)) << 8);
+        if (!isI4) w0 = w1 = w2 = w3 = w4 = dcMask = 0u;
+      }
+      if (HAS_I8 && is8) w0 = ((unsigned)M[0] << 3) | ((unsigned)M[2] << 11) | ((unsigned)M[8] << 19) | ((unsigned)M[10] << 27);
+      if (valid) {
+        unsigned* rec = recF + (size_t)MREC_WORDS * mb;
+        wv::st_g128_sc1(rec, u32x4{w0, w1, w2, w3});
+        wv::st_g128_sc1(rec + 4, u32x4{w4, 0u, dcMask, bottom});
+      }
+    }
+    wv::wave_sync();
+  }
+  // the records are complete once the last store has been written through
+  wv::wait_vm(0);
+  if (G.hasBelow && lane == 0) wv::st_sc1(myProgM, (unsigned)W);
+}
+
+// ==================================================================================================================
 // FRONT wave: records, luma residuals, mode derivation, the band above's luma lines for BACK
 // ==================================================================================================================
 template <bool HAS_I8, bool WIDE>
@@ -684,14 +841,11 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
   const int pitchY = W * 16;
   const size_t frameBytes = (size_t)W * H * 384;
   unsigned gstep = 0;  // steps of this team so far, over all its tasks: buffer = parity, flags carry gstep + 1
-  // FRONT is the wave at the register limit: its lane roles are recomputed in every step, except these four, which save
+  // FRONT is the wave at the register limit: its lane roles are recomputed in every step, except these, which save
   // the most arithmetic per register (kept behind an optimisation barrier)
   const int hi4 = lane0 & 15, hzbx = ((hi4 >> 1) & 2) | (hi4 & 1), hzby = ((hi4 >> 2) & 2) | ((hi4 >> 1) & 1);
   const int hPermDc = wv::opaque((lane0 & 48) + zidx((0x1320 >> (4 * hzbx)) & 3, (0x1320 >> (4 * hzby)) & 3));  // Intra16x16 DC: source lane of the last stage
   const int hResOff = wv::opaque(512 * (lane0 >> 4) + 32 * (4 * hzby + hzbx));                                   // this lane's block in the residual record
-  const int hMzb4 = wv::opaque(4 * zidx(hi4 & 3, hi4 >> 2));                                                     // 4 x blkIdx of its mode-grid position
-  const int ht4 = (hi4 & 3) + 2 * (hi4 >> 2);
-  const int hSeqOff = wv::opaque(24 * (lane0 >> 4) + 12 * ((hi4 >> 2) != stepByLo(ht4) ? 1 : 0) + ht4);          // its byte of the chain's table-row sequence
 
   for (unsigned seq = 0;; seq++) {
     // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
@@ -726,11 +880,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
     const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
-    uint8_t* const modesF = (uint8_t*)(A.rowModes + mbFrame);
-    unsigned* const myProg = A.progM + (size_t)G.f * nBands + G.b;
-    const unsigned* const upProgM = myProg - 1;
+    unsigned* const recF = A.rowModes + mbFrame * MREC_WORDS;   // the frame's mode records
+    unsigned* const myProgM = A.progM + (size_t)G.f * nBands + G.b;
     const unsigned* const upProgY = A.progY + (size_t)G.f * nBands + G.b - 1;
-    const unsigned progYtoM = 4u * (unsigned)(A.progM - A.progY);  // in bytes (both in the workspace: one base and a lane offset for the pollers)
+
+    // ---- the band's prediction modes, all of them, before its first step
+    band_modes<HAS_I8>(P, A, G, task, ts, mbsF, recF, myProgM - 1, myProgM);
+    PH(6);  // mode pre-pass
 
     // ---- software pipeline: a step's record is fetched one step ahead (its first word, which decides the
     // coefficient layout, two steps ahead); its coefficients are fetched right after the previous step's residual
@@ -747,6 +903,11 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     auto load_kind = [&](int step) -> unsigned {
       const int l = lane0;
       return *(const unsigned*)(mbsF + 16u * mb_index(step, l >> 4));
+    };
+    // word i (0..7) of the mode record of row g's macroblock, on lanes 16 g + i (i < 8)
+    auto load_rec = [&](int step) -> unsigned {
+      const int l = lane0;
+      return wv::ld_sc1(recF + (MREC_WORDS * mb_index(step, l >> 4) + (unsigned)(l & 7)));
     };
     u32x4 cA0, cA1;
     int dcA;
@@ -765,14 +926,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     };
     u32x4 dN1 = load_desc(0);
     unsigned kN2 = load_kind(1);
+    unsigned mN1 = load_rec(0);
     load_coefs_luma(0, dN1.x);
 
     PH(0);  // claim, prologue loads
-    int Mprev = 2;           // derived modes of the macroblock to the left on the raster block grid
-    unsigned upKnown = 0;    // what this wave knows of the band above's progress: min(luma lines, modes)
-    unsigned flagV = 0;      // the band above's progress words, fetched during the previous step
+    unsigned upKnown = 0;    // what this wave knows of the band above's progress (luma lines)
+    unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
     bool flagPend = false;
-    bool linePend = false;   // bottom-row modes of the band's last row were stored in the previous step, not yet published
     unsigned lineN = 0;      // the band above's words of macroblock s+1, requested during the previous step (haveN)
     bool haveN = false;
 
@@ -780,15 +940,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       TRACE(1, s + 1);
       const int buf = (int)(gstep & 1u);
       const u32x4 dCur = dN1;
-      const unsigned kN1 = kN2;  // first record word of step s+1
+      const unsigned mCur = mN1;  // this lane's word of the step's mode record
+      const unsigned kN1 = kN2;   // first record word of step s+1
       // lane roles (see the pipeline comment above)
       const int lane = wv::opaque(lane0);
       const int g = lane >> 4, i = lane & 15;
       const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
-      const int rbx = i & 3, rby = i >> 2;                                              // mode grid: raster
-      const int r = r0 + g;
       const bool rowOk = g < nR;
-      const bool mbB = r > 0;
       const int x = s - 2 * g;
       const bool valid = rowOk && (unsigned)x < (unsigned)W;
       const bool needUp = hasAbove && s < W;
@@ -798,18 +956,16 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       int kind = (int)(dCur.x & 0xffu);
       const int i16mode = (int)((dCur.x >> 8) & 0xffu), cmodeL = (int)((dCur.x >> 16) & 0xffu);
       int qp = (int)(dCur.x >> 24);
-      const unsigned prevFlags = dCur.y & 0xffffu;
-      // the sixteen 4-bit rem fields (bytes 6..13 of the record) as two words: fields 0..7, 8..15
-      const unsigned remLo = wv::alignbit(dCur.z, dCur.y, 16), remHi = wv::alignbit(dCur.w, dCur.z, 16);
       if (kind > 2 || (!HAS_I8 && kind == 1) || qp > 51 || i16mode > 3 || cmodeL > 3) {
         if (valid && i == 0) wv::atomic_or(A.status, 1u);
         kind = 3;
         qp = 0;
       }
-      const bool mbA = x > 0, mbC = mbB && (x + 1 < W);
-      // the record of step s+1, the first record word of step s+2: requested now, a whole step before they are needed
+      // the record of step s+1 (and its mode record), the first record word of step s+2: requested now, a whole step
+      // before they are needed
       dN1 = load_desc(s + 1);
       kN2 = load_kind(s + 2);
+      mN1 = load_rec(s + 1);
 
       PH(1);  // record decode
       // ================= residuals ================================================================================
@@ -856,45 +1012,31 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       }
       PH(2);  // luma residuals
       // ---- hand-off traffic, placed here so that nothing in front of the residuals waits for it.
-      // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom-row modes.
-      // It has had a residual pass to drain; once vmcnt says that everything this wave has issued is done (loads and
-      // stores count together, in order) the macroblock is published.
-      if (linePend) {
-        wv::wait_vm(0);
-        const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
-        if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
-        linePend = false;
-      }
-      // lanes 0..4: macroblock s+1 of the band above's last row (0..3 bottom luma line, 4 modes); lanes 16..20:
-      // macroblock 0 at step 0. When the band above is far enough ahead, macroblock s+2 is requested as well and kept in
-      // a register until the next step: the request then has a whole step to come back (haveN / lineN).
+      // lanes 0..3: bottom luma line of macroblock s+1 of the band above's last row; lanes 16..19: of macroblock 0 at step
+      // 0. When the band above is far enough ahead, macroblock s+2 is requested as well and kept in a register until
+      // the next step: the request then has a whole step to come back (haveN / lineN).
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
-      const bool fetchLane = needUp && li < 5 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-      // (two loads off wave-uniform bases, each under its lanes' mask, rather than one load off a per-lane choice of
-      // pointer: that would be 64-bit vector arithmetic)
+      const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
       auto fetch_up = [&](int mb) -> unsigned {
-        unsigned v = 0;
-        if (li < 4) v = wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mb + 4 * li)));
-        if (li == 4) v = wv::ld_sc1((const unsigned*)(modesF + 4u * (unsigned)((r0 - 1) * W + mb)));
-        return v;
+        return wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mb + 4 * li)));
       };
       bool haveNext = false;
       if (needUp && !EXP_SKIP(2)) {
-        // the band above must have finished macroblock s+1 (luma: BACK's neighbour C; modes) before they are fetched.
-        // Its progress words are read one step ahead (flagV), so this normally costs nothing; otherwise poll.
-        if (flagPend) upKnown = max(upKnown, min((unsigned)wv::rfl((int)flagV), (unsigned)wv::rdlane((int)flagV, 32)));
+        // the band above must have finished macroblock s+1 (BACK's neighbour C) before its line is fetched. Its progress
+        // word is read one step ahead (flagV), so this normally costs nothing; otherwise poll.
+        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
         flagPend = false;
-        upKnown = poll_progress(upProgY, upProgM, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
+        upKnown = poll_progress(upProgY, upProgY, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
         wv::compiler_fence();
         if (fetchLane) {
           if (haveN && lane < 16) lineV = lineN;
           else lineV = fetch_up(mbx);
         }
         haveNext = s + 2 < W && upKnown >= (unsigned)(s + 3);
-        if (haveNext && lane < 16 && li < 5) lineN = fetch_up(s + 2);
+        if (haveNext && lane < 16 && li < 4) lineN = fetch_up(s + 2);
         if (upKnown < (unsigned)W) {
-          flagV = wv::ld_sc1((const unsigned*)((const uint8_t*)upProgY + (lane < 32 ? 0u : progYtoM)));
+          flagV = wv::ld_sc1(upProgY);
           flagPend = true;
         }
       }
@@ -927,98 +1069,21 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         wv::lds_st32(ts + S_INFO + 32 * buf + 16, task);
         wv::lds_st32(ts + S_INFO + 32 * buf + 20, (unsigned)s);
         wv::lds_st32(ts + S_INFO + 32 * buf + 24, seq & 1u);
-        wv::lds_st32(ts + S_INFO + 32 * buf + 28, 0u);  // rounds of the block chain that have a DC block: see below
+        wv::lds_st32(ts + S_INFO + 32 * buf + 28, 0u);  // rounds of the block chain that have a DC block: below
       }
-      // what was fetched from the band above goes into row 0's rings (BACK's luma ring, the modes ring): at step 0 now
-      // (macroblock 0 is this step's neighbour B), otherwise behind the mode derivation, which hides the fetch
-      auto store_fetched = [&]() {
-        if (fetchLane) wv::lds_st32(li < 4 ? ringy(ts, 0, mbx, (int)(seq & 1u)) + 4 * li : ts + S_RINGM + 4 * (mbx & 3), lineV);
-      };
-      if (s == 0) store_fetched();
+      // what was fetched from the band above goes into row 0's luma ring (BACK's)
+      if (fetchLane) wv::lds_st32(ringy(ts, 0, mbx, (int)(seq & 1u)) + 4 * li, lineV);
       wv::wave_sync();
-
-      // ================= Intra4x4 prediction modes (8.3.1.1, pred4x4.rs:363-427) ==================================
-      // mode grid = raster block grid, one DPP row per macroblock. Relaxation: after sweep k every block with
-      // bx + by <= k is final.
-      int Mcur = 2;
-      // Intra8x8 (8.3.2.1, pred8x8.rs:698-764): each 8x8 block fills its four grid positions with its mode; the block's
-      // top-left position derives it exactly like a 4x4 block there would (its A is the position left of the block's
-      // first row, its B the one above its first column), the other three copy it after every sweep.
-      const bool anyI4 = !EXP_SKIP(1) && wv::any(valid && (kind == 0 || (HAS_I8 && kind == 1)));
-      if (anyI4) {
-        const bool is8 = HAS_I8 && kind == 1;
-        const int mzb = is8 ? 2 * (rby >> 1) + (rbx >> 1) : hMzb4 >> 2;
-        const int rem = (int)(((mzb < 8 ? remLo : remHi) >> (4 * (mzb & 7))) & 7u);
-        const bool prev = ((prevFlags >> mzb) & 1u) != 0;
-        const unsigned upM = mbB ? wv::lds_u32(ts + S_RINGM + 16 * g + 4 * (x & 3)) : 0x02020202u;
-        const int Tb = (int)((upM >> (8 * rbx)) & 0xffu);
-        const int Lb = wv::dpp<DPP_ROW_SHL(3)>(Mprev, Mprev);
-        const bool unav = (rbx == 0 && !mbA) || (rby == 0 && !mbB);
-        // Neighbours as one min3 of DPP operands (modes are 0..8, 15 stands for "none"):
-        //   B: the lane one grid row up; grid row 0 (lanes 0..3 of the DPP row: no source, reads 0) takes Tb by an OR
-        //   A: the lane to the left; column 0 gets its own lane by the quad permute, which an OR with 15 turns into "none",
-        //      and takes the macroblock to the left (or 2) through the third operand
-        const int TbTop = rby == 0 ? Tb : 0, col0 = rbx == 0 ? 15 : 0, Aout = rbx == 0 ? (mbA ? Lb : 2) : 15;
-        int M = 2;
-#pragma unroll
-        for (int itr = 0; itr < 7; itr++) {
-          const int Am = wv::dppx<DPP_QUAD(0, 0, 1, 2)>(M) | col0;
-          const int Bm = wv::dppz<DPP_ROW_SHR(4)>(M) | TbTop;
-          const int pm = unav ? 2 : min(min(Am, Bm), Aout);
-          M = prev ? pm : (rem < pm ? rem : rem + 1);
-          if (HAS_I8) {
-            const int t = wv::dppx<DPP_QUAD(0, 0, 2, 2)>(M);        // the even column's value
-            const int u = wv::dpp<DPP_ROW_SHR(4)>(t, t);            // ... of the grid row above
-            if (is8) M = (rby & 1) ? u : t;
-          }
-        }
-        int Mp = M;
-        {
-          // quirk Q4: a mode whose reference samples are missing leaves the zero-initialised prediction
-          const bool topAv = rby > 0 || mbB, leftAv = rbx > 0 || mbA;
-          const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
-          const int req = (int)((0x217771021ull >> (4 * M)) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
-          if ((req & ~have) != 0) Mp = 9;
-          // modes 3 and 7 without a top-right block: T4..T7 := T3 (table rows 10 and 11)
-          const unsigned trBlocks = 0x5750u | (mbB ? 0x7u : 0u) | (mbC ? 0x8u : 0u);
-          if (!((trBlocks >> i) & 1u)) Mp = Mp == 3 ? 10 : Mp == 7 ? 11 : Mp;
-        }
-        if (kind == 0) {
-          Mcur = M;
-          const int t = rbx + 2 * rby;
-          wv::lds_st8(ts + S_MSEQ + 96 * buf + hSeqOff, (unsigned)(8 * Mp));  // (the table row's offset)
-          // BACK skips the DC arithmetic (and its samples) in the rounds where no block of the step is predicted DC
-          if (valid && Mp == 2) wv::lds_or32(ts + S_INFO + 32 * buf + 28, 1u << t);
-        } else if (is8) {
-          Mcur = M;
-          if (((rbx | rby) & 1) == 0) wv::lds_st8(ts + S_MSEQ + 96 * buf + 24 * g + mzb, (unsigned)(8 * M));  // BACK: modes of blocks 0..3 (x 8: see S_MSEQ)
-        }
+      // the step's modes from the band's pre-pass (band_modes): words 0..5 of the macroblock's mode record are the table
+      // rows of BACK's block chain (S_MSEQ), word 6 the chain rounds that have a DC block -- BACK skips the DC arithmetic
+      // (and its samples) in the rounds where no block of the step is predicted DC
+      if (valid && !EXP_SKIP(1)) {
+        if (i < 6) wv::lds_st32(ts + S_MSEQ + 96 * buf + 24 * g + 4 * i, mCur);
+        if (i == 6 && kind == 0) wv::lds_or32(ts + S_INFO + 32 * buf + 28, mCur);
       }
-
-      if (s != 0) store_fetched();
       wv::wave_sync();
       if (lane == 0) wv::lds_st32(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);  // the record is complete
-      PH(4);  // record for BACK, modes
-
-      // bottom-row modes for the row below (ring) or the band below (write-through)
-      {
-        unsigned m4 = (unsigned)Mcur << (8 * (i & 3));
-        m4 |= (unsigned)xor1((int)m4);
-        m4 |= (unsigned)xor2((int)m4);  // lanes 12..15 of the row group: the four bottom-row modes
-        if (valid && i == 12 && g < 3 && g < gl) wv::lds_st32(ts + S_RINGM + 16 * (g + 1) + 4 * (x & 3), m4);
-        if (hasBelow && wv::any(valid && g == gl)) {
-          if (valid && g == gl && i == 12) wv::st_sc1((unsigned*)(modesF + 4u * (unsigned)(r * W + x)), m4);
-          linePend = true;
-        }
-      }
-      Mprev = valid ? Mcur : 2;
-      wv::wave_sync();
-      PH(5);  // modes hand-off
-    }
-    // the band's modes are complete once the last store has been written through
-    if (hasBelow) {
-      wv::wait_vm(0);
-      if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
+      PH(4);  // record for BACK
     }
     TRACE(6, task + 1u);
   }

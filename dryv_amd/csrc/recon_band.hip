@@ -66,13 +66,13 @@ size_t band_lds_bytes(bool hasI8, int teams) { return (size_t)(hasI8 ? band::T_E
 int band_teams_per_block(bool hasI8, bool wide) { return (hasI8 || wide) ? (band::TEAMS_PER_WG < 3 ? band::TEAMS_PER_WG : 3) : band::TEAMS_PER_WG; }
 int band_blocks_per_cu() { return DRYV_BAND_WGS_PER_CU; }
 
-// Workspace: [task counter | pad to 256][luma | chroma | modes progress words | pad to 256][bottom-row modes]
+// Workspace: [task counter | pad to 256][luma | chroma | modes progress words | pad to 256][mode records, 32 bytes per macroblock]
 // [diagnostics]
 static size_t band_prog_words(const KParams& P) { return (size_t)P.n_frames * ((P.H + 3) / 4); }
 static size_t band_prog_bytes(const KParams& P) { return (3 * band_prog_words(P) * 4 + 255) & ~(size_t)255; }
 size_t band_reset_bytes(const KParams& P) { return 256 + band_prog_bytes(P); }
 size_t band_profile_offset(const KParams& P) {
-  return (256 + band_prog_bytes(P) + (size_t)P.n_frames * P.W * P.H * 4 + 255) & ~(size_t)255;
+  return (256 + band_prog_bytes(P) + (size_t)P.n_frames * P.W * P.H * (4 * band::MREC_WORDS) + 255) & ~(size_t)255;
 }
 size_t band_workspace_bytes(const KParams& P) { return band_profile_offset(P); }
 

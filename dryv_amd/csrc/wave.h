@@ -17,6 +17,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_ROW_ROR(n) (0x120 + (n))
 #define DPP_ROW_HALF_MIRROR 0x141   // lane i of every eight <- lane 7 - i
+#define DPP_WAVE_SHR1 0x138         // lane i <- lane i - 1 across the whole wave; lane 0 has no source
 
 #ifndef DRYV_EMU
 // =====================================================================================================
@@ -128,6 +129,8 @@ struct __attribute__((packed, aligned(4))) U128a4 { u32x4 v; };
 struct __attribute__((packed, aligned(4))) U64a4 { u32x2 v; };
 WV void st_g128(void* p, u32x4 v) { ((U128a4*)p)->v = v; }  // dword-aligned 16-byte store (global_store_dwordx4)
 WV void st_g64(void* p, u32x2 v) { ((U64a4*)p)->v = v; }
+// 16-byte write-through store (global_store_dwordx4 ... sc1): for bytes another workgroup loads with sc1 loads
+WV void st_g128_sc1(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 // all but the n youngest vector-memory operations of this wave have completed (n wave-uniform, 0..8)
 WV void wait_vm(int n) {
   switch (n) {
@@ -190,6 +193,7 @@ WV int emu_dpp_src(int ctrl, int lane) {
   if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; return i - n >= 0 ? row + i - n : -1; }
   if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl - 0x120; return row + ((i - n) & 15); }
   if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));
+  if (ctrl == 0x138) return lane - 1;
   fprintf(stderr, "emu: unsupported dpp ctrl %x\n", ctrl);
   abort();
 }
@@ -327,6 +331,7 @@ WV void atomic_or(unsigned* p, unsigned v) { *p |= v; }
 WV u32x4 ld_u128_a2(const void* p) { u32x4 v; memcpy(&v, p, 16); return v; }
 WV void st_g128(void* p, u32x4 v) { memcpy(p, &v, 16); }
 WV void st_g64(void* p, u32x2 v) { memcpy(p, &v, 8); }
+WV void st_g128_sc1(void* p, u32x4 v) { memcpy(p, &v, 16); }
 WV void wait_vm(int) {}
 // a poll that failed: the wave yields to the other emulated waves (all 64 lanes get here together)
 WV void sleep_short() { emu_barrier("@sleep"); }

@@ -129,7 +129,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
   const int WPT = dryv::band::WAVES_PER_TEAM;
   const int n_waves = WPT * n_teams;
   const int nBands = (g_P.H + 3) / 4;
-  std::vector<unsigned> prog((size_t)3 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H, 0xEEEEEEEEu);
+  std::vector<unsigned> prog((size_t)3 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H * dryv::band::MREC_WORDS, 0xEEEEEEEEu);
   // like the host API: the fast build first; if it flags a block beyond int32 (status bit 1), the batch again with the wide build
   unsigned status[4] = {0, 0, 0, 0};
   for (int pass = 0; pass < 2; pass++) {
