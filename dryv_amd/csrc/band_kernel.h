@@ -89,8 +89,9 @@ constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [4 * 
 constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       8 x the Intra4x4 table row per chain step and block half (always a multiple of 8)
 constexpr int S_INFO = 4288;     // u32 [2][8]              kinds of the 4 macroblocks, Intra16x16 modes, task, step, parity, chain rounds with a DC block
 constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2] (global step count + 1 of the record in / consumed from the
-                                 //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks)
-constexpr int F_READY = 0, F_FREE = 8, F_TASKS = 16, F_HEAD = 32, F_TAILC = 36;
+                                 //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks),
+                                 //     modesDone (CHROMA -> FRONT: tasks whose mode pre-pass is through)
+constexpr int F_READY = 0, F_FREE = 8, F_TASKS = 16, F_HEAD = 32, F_TAILC = 36, F_MODES = 40;
 // BACK (+ FRONT writes row 0 of the luma ring: lines fetched from the band above)
 constexpr int S_TILE = 4416;     // u8  [4][NP][TILE_BYTES]  luma: tile (x >> 1) % NP, row j = y + 1, column 8 + 16 * (x & 1) + xr
 constexpr int S_RINGY = S_TILE + 4 * NP * TILE_BYTES;  // bottom luma lines of the row above: row 0 [2][8][16], rows 1..3 [4][16]
@@ -125,6 +126,20 @@ WV int ringy(int ts, int g, int e, int par) {
 constexpr int TEAMS_PER_WG = DRYV_BAND_TEAMS;
 constexpr int WAVES_PER_TEAM = 3;  // FRONT, BACK, CHROMA
 constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
+// wave priorities by role (recon_band.hip); FRONT raises its own for the mode pre-pass of a task, when the other two
+// waves of the team have nothing to do until it is through
+#ifndef DRYV_BAND_PRIO_BACK
+#define DRYV_BAND_PRIO_BACK 2
+#endif
+#ifndef DRYV_BAND_PRIO_CHROMA
+#define DRYV_BAND_PRIO_CHROMA 2
+#endif
+#ifndef DRYV_BAND_PRIO_FRONT
+#define DRYV_BAND_PRIO_FRONT 0
+#endif
+#ifndef DRYV_BAND_PRIO_MODES
+#define DRYV_BAND_PRIO_MODES 3
+#endif
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a progress word (about a second) before a band gives up
 constexpr unsigned TASK_END = 0xFFFFFFFFu;
 
@@ -695,21 +710,36 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
   if (G.hasAbove) poll_progress(upProgM, upProgM, 0u, (unsigned)W, (unsigned)W, A.status, task, -1, lane);
   if (lane < 4) wv::lds_st32(ts + S_CARRYM + 4 * lane, 0x02020202u);
   wv::wave_sync();
+  // One iteration = 64 macroblocks of one row: batch after batch, the band's rows inside a batch (row g's neighbour B
+  // is the same lane one iteration earlier). The next iteration's records are requested before this one's arithmetic.
+  const int nR = G.nR, nIter = ((W + 63) >> 6) * nR;
+  auto mb_of = [&](int it) -> unsigned {   // this lane's macroblock in iteration `it` (the last one of the row beyond it)
+    const int xb = it / nR, gg = it - xb * nR;
+    return (unsigned)((G.r0 + gg) * W + min(64 * xb + lane, W - 1));
+  };
+  auto load_top = [&](int it) -> unsigned {  // row 0's neighbour B: the band above's bottom grid row
+    const unsigned mbn = mb_of(it);
+    return (G.hasAbove && it % nR == 0) ? wv::ld_sc1(recF + (size_t)MREC_WORDS * (mbn - (unsigned)W) + 7) : 0x02020202u;
+  };
+  u32x4 dNext = wv::ld_u128_a2(mbsF + 16u * mb_of(0));
+  unsigned topNext = load_top(0);
+  unsigned bottom = 0x02020202u;  // raw modes of the bottom grid row of the macroblock above (same lane, previous iteration)
 #pragma clang loop unroll(disable)
-  for (int x0 = 0; x0 < W; x0 += 64) {
+  for (int it = 0; it < nIter; it++) {
+    const int xb = it / nR, g = it - xb * nR, x0 = 64 * xb;
     const int x = x0 + lane;
     const bool valid = x < W;
-    const int xc = min(x, W - 1);
     const bool xIs0 = x == 0, xLast = x + 1 >= W;
-    unsigned bottom = 0x02020202u;  // raw modes of the bottom grid row of the macroblock above (same lane)
-#pragma clang loop unroll(disable)
-    for (int g = 0; g < G.nR; g++) {
+    {
       const int r = G.r0 + g;
       const bool rowTop = r > 0;  // (wave-uniform) macroblock B exists
-      const unsigned mb = (unsigned)(r * W + xc);
-      const u32x4 d = wv::ld_u128_a2(mbsF + 16u * mb);
-      unsigned topM = bottom;
-      if (g == 0 && rowTop) topM = wv::ld_sc1(recF + (size_t)MREC_WORDS * (mb - (unsigned)W) + 7);
+      const unsigned mb = mb_of(it);
+      const u32x4 d = dNext;
+      const unsigned topM = g == 0 ? topNext : bottom;
+      if (it + 1 < nIter) {
+        dNext = wv::ld_u128_a2(mbsF + 16u * mb_of(it + 1));
+        topNext = load_top(it + 1);
+      }
       const unsigned carry = wv::lds_u32(ts + S_CARRYM + 4 * g);
       // the record checks of the step (an unsupported record reconstructs as zero and counts as DC for its neighbours)
       int kind = (int)(d.x & 0xffu);
@@ -816,7 +846,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
         wv::st_g128_sc1(rec + 4, u32x4{w4, 0u, dcMask, bottom});
       }
     }
-    wv::wave_sync();
+    if (g == nR - 1) wv::wave_sync();  // (lane 63's right columns: the next batch's macroblock A)
   }
   // the records are complete once the last store has been written through
   wv::wait_vm(0);
@@ -847,19 +877,31 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
   const int hPermDc = wv::opaque((lane0 & 48) + zidx((0x1320 >> (4 * hzbx)) & 3, (0x1320 >> (4 * hzby)) & 3));  // Intra16x16 DC: source lane of the last stage
   const int hResOff = wv::opaque(512 * (lane0 >> 4) + 32 * (4 * hzby + hzbx));                                   // this lane's block in the residual record
 
-  for (unsigned seq = 0;; seq++) {
-    // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
-    // a single-lane conditional in front of a readfirstlane invites the compiler to thread that condition through the
-    // loop, after which the readfirstlane executes under a partial exec mask and returns another lane's value.
+  // Claims the task of sequence number q of this team and hands it to CHROMA (a ring of four task numbers).
+  // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
+  // a single-lane conditional in front of a readfirstlane invites the compiler to thread that condition through the
+  // loop, after which the readfirstlane executes under a partial exec mask and returns another lane's value.
+  auto claim_push = [&](unsigned q) -> unsigned {
     const unsigned tsk = wv::atomic_add_task(A.taskCounter, lane0 == 0 ? 1u : 0u);
-    const unsigned task = (unsigned)wv::rfl((int)tsk);
-    const bool last = task >= totalTasks;
-    // CHROMA follows through a ring of four task numbers
-    if (seq >= 4) team_wait_ge(ts + S_FLAGS + F_TAILC, seq - 3);
-    if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_TASKS + 4 * (int)(seq & 3u), last ? TASK_END : task);
+    unsigned t = (unsigned)wv::rfl((int)tsk);
+    if (t >= totalTasks) t = TASK_END;
+    if (q >= 4) team_wait_ge(ts + S_FLAGS + F_TAILC, q - 3);
+    if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_TASKS + 4 * (int)(q & 3u), t);
     wv::wave_sync();
-    if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_HEAD, seq + 1);
-    if (last) {
+    if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_HEAD, q + 1);
+    return t;
+  };
+  // A task is claimed CLAIM_AHEAD steps before the previous one ends: CHROMA, which runs ahead of the luma waves inside a
+  // task and used to wait for the next one, derives the next band's prediction modes (band_modes) in that time. (Any
+  // unfinished task with the smallest number is some team's current one and waits only for smaller ones: no deadlock.)
+#ifndef DRYV_BAND_CLAIM_AHEAD
+#define DRYV_BAND_CLAIM_AHEAD 24
+#endif
+  unsigned nextTask = claim_push(0u);
+  for (unsigned seq = 0;; seq++) {
+    const unsigned task = nextTask;
+    bool claimedNext = false;
+    if (task == TASK_END) {
       // tell BACK to stop: an end record in the next buffer
       const int buf = (int)(gstep & 1u);
       if (gstep >= 2) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - 1);
@@ -880,13 +922,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
     const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
-    unsigned* const recF = A.rowModes + mbFrame * MREC_WORDS;   // the frame's mode records
-    unsigned* const myProgM = A.progM + (size_t)G.f * nBands + G.b;
+    const unsigned* const recF = A.rowModes + mbFrame * MREC_WORDS;   // the frame's mode records
     const unsigned* const upProgY = A.progY + (size_t)G.f * nBands + G.b - 1;
+    const int claimStep = max(nSteps - DRYV_BAND_CLAIM_AHEAD, 0);
 
-    // ---- the band's prediction modes, all of them, before its first step
-    band_modes<HAS_I8>(P, A, G, task, ts, mbsF, recF, myProgM - 1, myProgM);
-    PH(6);  // mode pre-pass
+    // the band's prediction modes, all of them, are derived before its first step (CHROMA: band_modes)
+    team_wait_ge(ts + S_FLAGS + F_MODES, seq + 1);
+    PH(6);  // wait for the mode pre-pass
 
     // ---- software pipeline: a step's record is fetched one step ahead (its first word, which decides the
     // coefficient layout, two steps ahead); its coefficients are fetched right after the previous step's residual
@@ -938,6 +980,10 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
 
     for (int s = 0; s < nSteps; s++, gstep++) {
       TRACE(1, s + 1);
+      if (s == claimStep) {
+        nextTask = claim_push(seq + 1);
+        claimedNext = true;
+      }
       const int buf = (int)(gstep & 1u);
       const u32x4 dCur = dN1;
       const unsigned mCur = mN1;  // this lane's word of the step's mode record
@@ -1085,6 +1131,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       if (lane == 0) wv::lds_st32(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);  // the record is complete
       PH(4);  // record for BACK
     }
+    if (!claimedNext) nextTask = claim_push(seq + 1);
     TRACE(6, task + 1u);
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
@@ -1146,6 +1193,17 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
     unsigned* const myProg = A.progC + (size_t)G.f * nBands + G.b;
     const unsigned* const upProg = myProg - 1;
+
+    // ---- the band's prediction modes, all of them, before its first step: FRONT hands a task over well before the luma
+    // waves get to it, and this wave, ahead of them inside a task, has the time (band_modes)
+    {
+      unsigned* const myProgM = A.progM + (size_t)G.f * nBands + G.b;
+      wv::setprio<DRYV_BAND_PRIO_MODES>();
+      band_modes<HAS_I8>(P, A, G, task, ts, mbsF, A.rowModes + mbFrame * MREC_WORDS, myProgM - 1, myProgM);
+      wv::setprio<DRYV_BAND_PRIO_CHROMA>();
+      if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_MODES, seq + 1);
+    }
+    PH(5);  // mode pre-pass
 
     // Residuals are computed for two steps at a time, lanes 0..31 the even step's 32 blocks, lanes 32..63 the odd step's
     // (a residual pass costs the same for 32 lanes as for 64); prediction then runs on the half whose step it is.

@@ -41,15 +41,6 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5
   // batch (tools/band_variants.sh, same box within a line): no priorities 1.444 ms / BACK 2: 1.388 / BACK 3: 1.397;
   // BACK 2: 1.433 / BACK 2 + CHROMA 1: 1.373 / BACK = CHROMA = 2: 1.336-1.370 / 1, 1: 1.335-1.371 / 3, 2: 1.335-1.370;
   // FRONT raised with them, or alone: 1.47-1.49 (no gain or worse).
-#ifndef DRYV_BAND_PRIO_BACK
-#define DRYV_BAND_PRIO_BACK 2
-#endif
-#ifndef DRYV_BAND_PRIO_CHROMA
-#define DRYV_BAND_PRIO_CHROMA 2
-#endif
-#ifndef DRYV_BAND_PRIO_FRONT
-#define DRYV_BAND_PRIO_FRONT 0
-#endif
   if (role == 1 && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
   if (role == 2 && DRYV_BAND_PRIO_CHROMA) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_CHROMA);
   if (role == 0 && DRYV_BAND_PRIO_FRONT) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_FRONT);

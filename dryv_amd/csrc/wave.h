@@ -155,6 +155,9 @@ WV void sleep_long() { __builtin_amdgcn_s_sleep(32); }
 #endif
 WV void sleep_team() { __builtin_amdgcn_s_sleep(DRYV_TEAM_SLEEP); }  // between two polls of the partner wave's LDS flag
 WV void compiler_fence() { asm volatile("" ::: "memory"); }
+// wave priority for the SIMD's issue arbiter (s_setprio 0..3)
+template <int P>
+WV void setprio() { __builtin_amdgcn_s_setprio(P); }
 // the value, behind a barrier the optimiser cannot see through: what is derived from it is recomputed, not kept live
 WV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
@@ -338,6 +341,8 @@ WV void sleep_short() { emu_barrier("@sleep"); }
 WV void sleep_long() { emu_barrier("@sleep"); }
 WV void sleep_team() { emu_barrier("@sleep"); }
 WV void compiler_fence() {}
+template <int P>
+WV void setprio() {}
 WV int opaque(int v) { return v; }
 
 }  // namespace wv

@@ -19,9 +19,10 @@ from dryv_amd import _build, abi, synth  # noqa: E402
 
 ROLES = ["FRONT", "BACK", "CHROMA"]   # wave w of a workgroup: role w % 3 (recon_band.hip)
 PHASES = {
-    "FRONT": ["claim+prologue", "record decode", "luma residuals", "hand-off+prefetch", "record for BACK, modes",
-              "desc prefetch, modes hand-off"],
-    "CHROMA": ["task+prologue", "hand-off traffic", "chroma residuals+prefetch", "chroma prediction", "lines+copies+flush"],
+    "FRONT": ["claim+prologue", "record decode", "luma residuals", "hand-off+prefetch", "record for BACK (incl. wait for a free buffer)",
+              "-", "wait for the mode pre-pass (per task, here per step)"],
+    "CHROMA": ["task+prologue", "hand-off traffic", "chroma residuals+prefetch", "chroma prediction", "lines+copies+flush",
+               "mode pre-pass of the task (here per step)"],
     "BACK": ["wait for record", "top border", "intra16x16", "top-right+publish", "intra4x4 chain", "line+copies+flush"],
 }
 
