@@ -62,11 +62,16 @@ constexpr int T_THR8 = 408;   // u16 [52]
 constexpr int T_T4E = 512;    // u32 [8][12][2] Intra4x4 entries [pixel pair][mode][pixel]
 constexpr int T_LS4Q = 1280;  // u16 [52][16]   per qp: LevelScale4x4 << max(qp/6 - 4, 0) in list order, 0xFFFF where that needs 17 bits
 constexpr int T_LSMAX = 2944; // u16 [52]       per qp: the largest entry of its T_LS4Q row
-constexpr int T_END = 3072;
-constexpr int T_LS8 = 3072;   // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
-constexpr int T_T8 = 3840;    // u8  [9][64]    Intra8x8 table [mode][y*8+x]: index on the filtered edge | value kind << 5
-constexpr int T_ZZ8 = 4416;   // u8  [64]       8x8 list index -> 2 * raster position
-constexpr int T_END_I8 = 4480;
+constexpr int T_QP = 3072;    // u32 [52][8]    per qp, what a 4x4 residual pass derives from it: [0] rounding term and [1] right shift
+                              //                of the packed path (both halves), [2] T_LSMAX | T_THR4 << 16, [3] shl | rnd << 8 |
+                              //                shr << 16 | (32 * (qp % 6)) << 24; DC terms: [4] LevelScale(0,0), [5] qp / 6,
+                              //                [6] rounding term and [7] shl | shr << 8 of the Intra16x16 DC scaling
+constexpr int T_END = 4736;
+constexpr int T_LS8 = T_END;          // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
+constexpr int T_T8 = T_LS8 + 768;     // u8  [9][64]    Intra8x8 table [mode][y*8+x]: index on the filtered edge | value kind << 5
+constexpr int T_ZZ8 = T_T8 + 576;     // u8  [64]       8x8 list index -> 2 * raster position
+constexpr int T_END_I8 = T_ZZ8 + 64;
+static_assert(T_END % 64 == 0 && T_END_I8 % 64 == 0, "table layout");
 
 // ---- per-team scratch in LDS (byte offsets from the team's base) ---------------------------------------------
 // Output staging: a row's pixels are flushed to global memory NSY (luma) / NSC (chroma) macroblocks at a time, as
@@ -245,7 +250,19 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
     const int qd = qp / 6, qm = qp - 6 * qd;
     unsigned m = 0;
     for (int k = 0; k < 16; k++) m = max(m, (unsigned)P.ls4z[16 * qm + k] << (qd > 4 ? qd - 4 : 0));
-    wv::lds_st16(ldsBase + T_LSMAX + 2 * qp, m > 0xFFFFu ? 0xFFFFu : m);
+    m = m > 0xFFFFu ? 0xFFFFu : m;
+    wv::lds_st16(ldsBase + T_LSMAX + 2 * qp, m);
+    // d = ((c * LS) << shl + rnd) >> shr with shl = max(qp/6 - 4, 0), shr = max(4 - qp/6, 0), rnd = 2^(3 - qp/6) below qp 24
+    const unsigned shl = qd > 4 ? qd - 4 : 0, shr = qd < 4 ? 4 - qd : 0, rnd = qd < 4 ? 1u << (3 - qd) : 0u;
+    wv::lds_st32(ldsBase + T_QP + 32 * qp, rnd * 0x10001u);
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 4, shr * 0x10001u);
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 8, m | ((unsigned)P.thr4[qp] << 16));
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 12, shl | (rnd << 8) | (shr << 16) | ((unsigned)(32 * qm) << 24));
+    // Intra16x16 DC (pred16x16.rs:465-479): qp >= 36: (f * LS) << (qp/6 - 6), else (f * LS + 2^(5 - qp/6)) >> (6 - qp/6)
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 16, (unsigned)P.ls4z[16 * qm]);
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 20, (unsigned)qd);
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 24, qd < 6 ? 1u << (5 - qd) : 0u);
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 28, (unsigned)(qd > 6 ? qd - 6 : 0) | ((unsigned)(qd < 6 ? 6 - qd : 0) << 8));
   }
   for (int k = tid; k < 192; k += nthreads) {
     // entry of (table row m, pixel pair p, pixel e): shift | DC flag << 5 | three tile offsets relative to
@@ -389,12 +406,11 @@ WV unsigned sum_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
   a = wv::sad_u16(c1.z, b, a);
   return 16u * 32768u - wv::sad_u16(c1.w, b, a);
 }
-WV bool block_fits16(const u32x4 c0, const u32x4 c1, int ldsBase, int qp, bool useDc, long long dcVal) {
+WV bool block_fits16(const u32x4 c0, const u32x4 c1, unsigned lsmax, bool useDc, int dc, bool dcHuge) {
   const unsigned sa = min(sum_abs16(c0, c1, useDc), 32768u);            // (<= 2^15: the product below fits 32 bits)
-  unsigned bound = sa * wv::lds_u16(ldsBase + T_LSMAX + 2 * qp);
+  unsigned bound = sa * lsmax;
   if (useDc) {
-    const int dc = (int)dcVal;
-    if ((long long)dc != dcVal || dc > 32767 || dc < -32767) return false;
+    if (dcHuge || dc > 32767 || dc < -32767) return false;
     bound += (unsigned)(dc < 0 ? -dc : dc);
   }
   return bound <= 32700u;
@@ -416,16 +432,19 @@ WV void butterfly_pk(const unsigned m[4], unsigned f[4]) {
   f[2] = wv::pk_sub(e1, e2);
   f[3] = wv::pk_sub(e0, e3);
 }
-// lq0/lq1: the qp's T_LS4Q row. rnd / shr as in idct4x4 (both 0 from qp 24 up: the shift is in the table).
-WV void idct4x4_pk16(const u32x4 c0, const u32x4 c1, const u32x4 lq0, const u32x4 lq1, int rnd, int shr, bool useDc, int dcVal,
-                     unsigned out[8]) {
+// lq0/lq1: the qp's T_LS4Q row. rnd2 / shr2: rnd / shr of idct4x4 in both halves (0 from qp 24 up: the shift is in the table).
+// inputsDone(): called as soon as the coefficient registers have been read for the last time (the caller's prefetch of the
+// next coefficients goes there: the earlier it is issued, the more of the step it has to come back).
+template <typename F>
+WV void idct4x4_pk16(const u32x4 c0, const u32x4 c1, const u32x4 lq0, const u32x4 lq1, unsigned rnd2, unsigned shr2, bool useDc, int dcVal,
+                     unsigned out[8], F&& inputsDone) {
   const unsigned cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
   const unsigned lw[8] = {lq0.x, lq0.y, lq0.z, lq0.w, lq1.x, lq1.y, lq1.z, lq1.w};
-  const unsigned rnd2 = (unsigned)rnd * 0x10001u, shr2 = (unsigned)shr * 0x10001u;
   unsigned z[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) z[k] = wv::pk_mad(cw[k], lw[k], rnd2);
-  if (wv::any(shr != 0)) {
+  inputsDone();
+  if (wv::any(shr2 != 0)) {
 #pragma unroll
     for (int k = 0; k < 8; k++) z[k] = wv::pk_ashr(z[k], shr2);
   }
@@ -465,29 +484,35 @@ WV int max_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
 // with the WIDE build before anything is reported -- the fast kernel carries no 64-bit code, which would cost it its
 // register budget; no conformant stream ever takes this route.
 // unused: this lane's result is not needed (an Intra8x8 macroblock's lanes): it must not keep the wave off the packed path.
-template <bool WIDE>
-WV void residual_pass(const u32x4 c0, const u32x4 c1, int ldsBase, int lsAddr, int qp, bool useDc, long long dcVal, int thr,
-                      bool unused, unsigned* status, unsigned out[8]) {
-  const int qd = (qp * 43) >> 8;
-  const int shl = max(qd - 4, 0), shr = max(4 - qd, 0), rnd = qd < 4 ? (1 << (3 - qd)) : 0;
-  if (!wv::any(!unused && !block_fits16(c0, c1, ldsBase, qp, useDc, dcVal))) {
+// The DC term that replaces entry 0 (useDc): dc when it fits 32 bits with room to spare (|dc| <= 2^26), else dcHuge (the
+// fast build then knows no more than that; the WIDE build carries the exact value in dcWide).
+template <bool WIDE, typename F>
+WV void residual_pass(const u32x4 c0, const u32x4 c1, int ldsBase, int qp, bool useDc, int dc, bool dcHuge, long long dcWide,
+                      bool unused, unsigned* status, unsigned out[8], F&& inputsDone) {
+  const u32x4 q = wv::lds_u128(ldsBase + T_QP + 32 * qp);   // everything the pass derives from qp (build_tables)
+  if (!wv::any(!unused && !block_fits16(c0, c1, q.z & 0xffffu, useDc, dc, dcHuge))) {
     const u32x4 lq0 = wv::lds_u128(ldsBase + T_LS4Q + 32 * qp), lq1 = wv::lds_u128(ldsBase + T_LS4Q + 32 * qp + 16);
-    idct4x4_pk16(c0, c1, lq0, lq1, rnd, shr, useDc, (int)dcVal, out);
+    idct4x4_pk16(c0, c1, lq0, lq1, q.x, q.y, useDc, dc, out, inputsDone);
     return;
   }
+  const int thr = unused ? 0xFFFF : (int)(q.z >> 16);
+  const int shl = (int)(q.w & 0xffu), rnd = (int)((q.w >> 8) & 0xffu), shr = (int)((q.w >> 16) & 0xffu);
+  const int lsAddr = ldsBase + T_LS4Z + (int)(q.w >> 24);   // LevelScale of qp % 6, list order
   bool big = false;
   if (wv::any(thr != 0xFFFF)) big = thr != 0xFFFF && max_abs16(c0, c1, useDc) > thr;
-  if (useDc && (dcVal > (1ll << 26) || dcVal < -(1ll << 26))) big = true;
+  if (useDc && (dcHuge || dc > (1 << 26) || dc < -(1 << 26))) big = true;
   if (WIDE) {
     if (wv::any(big)) {
-      idct4x4_wide(c0, c1, lsAddr, shl, rnd, shr, useDc, dcVal, out);
+      idct4x4_wide(c0, c1, lsAddr, shl, rnd, shr, useDc, dcWide, out);
+      inputsDone();
       return;
     }
   } else if (big) {
     wv::atomic_or(status, 2u);
   }
   const u32x4 l0 = wv::lds_u128(lsAddr), l1 = wv::lds_u128(lsAddr + 16);
-  idct4x4<int>(c0, c1, l0, l1, shl, rnd, shr, useDc, (int)dcVal, out);
+  idct4x4<int>(c0, c1, l0, l1, shl, rnd, shr, useDc, dc, out);
+  inputsDone();
 }
 
 // ---- 8x8 residuals of the step's Intra8x8 macroblocks (8.5.13, pred8x8.rs:51-150) ----------------------------------
@@ -694,9 +719,11 @@ WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned known
 //     right column changes (then every lane has seen its final inputs). A change only travels on when it flips a
 //     comparison, so two or three passes are the rule; the bound is one pass per lane.
 //   * Out: one 32-byte mode record per macroblock in global memory (workspace), in exactly the form the steps consume:
-//       bytes 0..23  the Intra4x4 chain's table rows x 8, [block half][chain round] (= S_MSEQ's layout; rows 9..11 =
+//       bytes 0..19  the Intra4x4 chain's table rows x 8, [block half][chain round] (= S_MSEQ's layout; rows 9..11 =
 //                    zero prediction of quirk Q4 / modes 3, 7 without a top-right block); an Intra8x8 macroblock:
 //                    bytes 0..3 = its four modes x 8
+//       word 5       the record's first word (kind, Intra16x16 / chroma modes, qp), checked: an unsupported record is
+//                    reported here (status bit 0) and reads as kind 3 / qp 0 from then on
 //       word 6       chain rounds of the macroblock that have a DC-predicted block (bit t)
 //       word 7       the raw modes of its bottom grid row (DC for any other macroblock kind): neighbour B of the row below
 //     written through (sc1) and published per band by one progress word (progM = W) for the band below; the band's own
@@ -743,7 +770,12 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
       const unsigned carry = wv::lds_u32(ts + S_CARRYM + 4 * g);
       // the record checks of the step (an unsupported record reconstructs as zero and counts as DC for its neighbours)
       int kind = (int)(d.x & 0xffu);
-      if (kind > 2 || (!HAS_I8 && kind == 1) || (d.x >> 24) > 51u || ((d.x >> 8) & 0xffu) > 3u || ((d.x >> 16) & 0xffu) > 3u) kind = 3;
+      unsigned word0 = d.x;   // kind | Intra16x16 mode << 8 | chroma mode << 16 | qp << 24: what the steps read (MREC word 5)
+      if (kind > 2 || (!HAS_I8 && kind == 1) || (d.x >> 24) > 51u || ((d.x >> 8) & 0xffu) > 3u || ((d.x >> 16) & 0xffu) > 3u) {
+        if (valid) wv::atomic_or(A.status, 1u);
+        kind = 3;
+        word0 = 3u;   // (kind 3, qp 0)
+      }
       const bool isI4 = kind == 0, is8 = HAS_I8 && kind == 1;
       // rem fields as nibbles in blkIdx order, bit 3 of a nibble set where prev_intra*_pred_mode_flag is: such a block
       // takes the predicted mode, and its "rem" of 8..15 is not below any mode
@@ -843,7 +875,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
       if (valid) {
         unsigned* rec = recF + (size_t)MREC_WORDS * mb;
         wv::st_g128_sc1(rec, u32x4{w0, w1, w2, w3});
-        wv::st_g128_sc1(rec + 4, u32x4{w4, 0u, dcMask, bottom});
+        wv::st_g128_sc1(rec + 4, u32x4{w4, word0, dcMask, bottom});
       }
     }
     if (g == nR - 1) wv::wave_sync();  // (lane 63's right columns: the next batch's macroblock A)
@@ -935,16 +967,19 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     // pass, into the registers that pass has just freed. Lane roles are recomputed from an opaque lane id wherever
     // they are needed: kept live across the step they would cost more registers than the few VALU they take.
     auto mb_index = [&](int step, int g) -> unsigned {  // within the frame
-      const int x = min(max(step - 2 * g, 0), W - 1);
+      const int x = wv::clamp3(step - 2 * g, 0, W - 1);
       return (unsigned)(min(r0 + g, H - 1) * W + x);
     };
-    auto load_desc = [&](int step) -> u32x4 {
-      const int l = lane0;
-      return wv::ld_u128_a2(mbsF + 16u * mb_index(step, l >> 4));
-    };
+    // (the record's first word comes checked from the mode record: band_modes)
     auto load_kind = [&](int step) -> unsigned {
       const int l = lane0;
+#ifdef DRYV_EXP_KIND_FROM_DESC
       return *(const unsigned*)(mbsF + 16u * mb_index(step, l >> 4));
+#elif defined(DRYV_EXP_KIND_PLAIN)
+      return *(recF + (MREC_WORDS * mb_index(step, l >> 4) + 5u));
+#else
+      return wv::ld_sc1(recF + (MREC_WORDS * mb_index(step, l >> 4) + 5u));
+#endif
     };
     // word i (0..7) of the mode record of row g's macroblock, on lanes 16 g + i (i < 8)
     auto load_rec = [&](int step) -> unsigned {
@@ -966,10 +1001,10 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       cA1 = wv::ld_u128_a2(coefF + (mo + (unsigned)off + 16u));
       dcA = *(const int16_t*)(coefF + (mo + 2u * (unsigned)ZZ4IDX(zby, zbx)));
     };
-    u32x4 dN1 = load_desc(0);
+    unsigned kN1 = load_kind(0);
     unsigned kN2 = load_kind(1);
     unsigned mN1 = load_rec(0);
-    load_coefs_luma(0, dN1.x);
+    load_coefs_luma(0, kN1);
 
     PH(0);  // claim, prologue loads
     unsigned upKnown = 0;    // what this wave knows of the band above's progress (luma lines)
@@ -985,9 +1020,9 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         claimedNext = true;
       }
       const int buf = (int)(gstep & 1u);
-      const u32x4 dCur = dN1;
+      const unsigned kCur = kN1;  // first record word of this step's macroblock (checked: band_modes)
       const unsigned mCur = mN1;  // this lane's word of the step's mode record
-      const unsigned kN1 = kN2;   // first record word of step s+1
+      kN1 = kN2;                  // ... of step s+1
       // lane roles (see the pipeline comment above)
       const int lane = wv::opaque(lane0);
       const int g = lane >> 4, i = lane & 15;
@@ -999,17 +1034,9 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       unsigned lineV = 0;
 
       // ---- record decode (lane-per-block luma organisation: row g) ------------------------------------------
-      int kind = (int)(dCur.x & 0xffu);
-      const int i16mode = (int)((dCur.x >> 8) & 0xffu), cmodeL = (int)((dCur.x >> 16) & 0xffu);
-      int qp = (int)(dCur.x >> 24);
-      if (kind > 2 || (!HAS_I8 && kind == 1) || qp > 51 || i16mode > 3 || cmodeL > 3) {
-        if (valid && i == 0) wv::atomic_or(A.status, 1u);
-        kind = 3;
-        qp = 0;
-      }
-      // the record of step s+1 (and its mode record), the first record word of step s+2: requested now, a whole step
-      // before they are needed
-      dN1 = load_desc(s + 1);
+      const int kind = (int)(kCur & 0xffu), i16mode = (int)((kCur >> 8) & 0xffu), qp = (int)(kCur >> 24);
+      // the mode record of step s+1, the first record word of step s+2: requested now, a whole step (two) before they are
+      // needed
       kN2 = load_kind(s + 2);
       mN1 = load_rec(s + 1);
 
@@ -1022,7 +1049,9 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       } else {
         // Intra16x16 luma DC: 8.5.10 (pred16x16.rs:428-482). Lane (bx,by) holds c[by][bx]; f = A c A = P (H c H) P^T
         // with H the natural-order Hadamard (butterflies over the lane bits) and A row k = H row s(k), s = [0,2,3,1]
-        long long dcY = 0;
+        int dcY = 0;
+        bool dcHuge = false;
+        long long dcWide = 0;
         if (wv::any(kind == 2)) {
           int v = dcA;
           int o = xor1(v);
@@ -1035,19 +1064,30 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           v = (zby & 2) ? o - v : v + o;
           const int fv = wv::bperm(v, hPermDc);  // lane (s(bx), s(by)) of the row group, s = [0, 2, 3, 1]
           // qp >= 36: (f*LS) << (qp/6-6), else (f*LS + 2^(5-qp/6)) >> (6-qp/6)   (pred16x16.rs:465-479)
-          const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
-          const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
-          const long long prod = (long long)fv * ls00;
-          dcY = qd >= 6 ? prod * (1ll << (qd - 6)) : (prod + (1ll << (5 - qd))) >> (6 - qd);
+          const u32x4 qq = wv::lds_u128(ldsBase + T_QP + 32 * qp + 16);
+          const int shlY = (int)(qq.w & 0xffu), shrY = (int)(qq.w >> 8);
+          if (WIDE) {
+            const long long prod = (long long)fv * (int)qq.x;
+            dcWide = (long long)(((unsigned long long)prod << shlY) + (unsigned long long)qq.z) >> shrY;
+            dcHuge = dcWide > (1ll << 26) || dcWide < -(1ll << 26);
+            dcY = (int)dcWide;
+          } else {
+            // |f| < 2^16, LevelScale(0,0) < 2^13 and shl <= 2 keep the product inside 32 bits; a larger f (no conformant
+            // stream has one) flags the batch for the WIDE build
+            dcHuge = (unsigned)(fv + 65535) > 131070u;
+            dcY = (int)(((unsigned)(fv * (int)qq.x) << shlY) + qq.z) >> shrY;
+          }
         }
-        const int qm = qp - 6 * ((qp * 43) >> 8);
         // (an Intra8x8 lane's result of this pass is not used: it must not raise the 4x4 overflow flag either)
-        const int thr4 = (HAS_I8 && kind == 1) ? 0xFFFF : (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qp);
-        residual_pass<WIDE>(cA0, cA1, ldsBase, ldsBase + T_LS4Z + 32 * qm, qp, kind == 2, dcY, thr4, HAS_I8 && kind == 1, A.status, rA);
+        // (the next step's coefficients are requested from inside the pass, as soon as this step's have been read. The Intra8x8
+        // pass below reads them again: such a stream requests them behind it)
+        const u32x4 cC0 = cA0, cC1 = cA1;
+        residual_pass<WIDE>(cC0, cC1, ldsBase, qp, kind == 2, dcY, kind == 2 && dcHuge, dcWide, HAS_I8 && kind == 1, A.status, rA,
+                            [&]() { if (!HAS_I8) load_coefs_luma(s + 1, kN1); });
         // Intra8x8 macroblocks: their lanes' rA becomes 16 residuals of one column per 8x8 block pass (residual8x8)
         if (HAS_I8 && wv::any(valid && kind == 1)) {
           unsigned r8[8];
-          residual8x8<WIDE>(cA0, cA1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, r8);
+          residual8x8<WIDE>(cC0, cC1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, r8);
 #pragma unroll
           for (int k = 0; k < 8; k++) rA[k] = kind == 1 ? r8[k] : rA[k];
         }
@@ -1087,7 +1127,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         }
       }
       haveN = haveNext;
-      load_coefs_luma(s + 1, kN1);  // (into the registers the residual pass has just freed)
+      if (HAS_I8 || EXP_SKIP(0)) load_coefs_luma(s + 1, kN1);  // (otherwise: requested inside the residual pass)
       PH(3);  // hand-off traffic, coefficient prefetch
 
       // ---- the step's record for BACK: residuals [blkIdx][y][x], table rows, kinds. The buffer is free once BACK has
@@ -1193,13 +1233,14 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
     unsigned* const myProg = A.progC + (size_t)G.f * nBands + G.b;
     const unsigned* const upProg = myProg - 1;
+    unsigned* const recF = A.rowModes + mbFrame * MREC_WORDS;   // the frame's mode records
 
     // ---- the band's prediction modes, all of them, before its first step: FRONT hands a task over well before the luma
     // waves get to it, and this wave, ahead of them inside a task, has the time (band_modes)
     {
       unsigned* const myProgM = A.progM + (size_t)G.f * nBands + G.b;
       wv::setprio<DRYV_BAND_PRIO_MODES>();
-      band_modes<HAS_I8>(P, A, G, task, ts, mbsF, A.rowModes + mbFrame * MREC_WORDS, myProgM - 1, myProgM);
+      band_modes<HAS_I8>(P, A, G, task, ts, mbsF, recF, myProgM - 1, myProgM);
       wv::setprio<DRYV_BAND_PRIO_CHROMA>();
       if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_MODES, seq + 1);
     }
@@ -1209,12 +1250,19 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     // (a residual pass costs the same for 32 lanes as for 64); prediction then runs on the half whose step it is.
     // Software pipeline as in FRONT: first record word and coefficients one pair of steps ahead.
     auto mb_index = [&](int step, int g) -> unsigned {  // within the frame
-      const int x = min(max(step - 2 * g, 0), W - 1);
+      const int x = wv::clamp3(step - 2 * g, 0, W - 1);
       return (unsigned)(min(r0 + g, H - 1) * W + x);
     };
+    // (the record's first word, checked, from the mode record: band_modes)
     auto load_kind = [&](int step) -> unsigned {
       const int l = lane0;
+#ifdef DRYV_EXP_KIND_FROM_DESC
       return *(const unsigned*)(mbsF + 16u * mb_index(step + (l >> 5), (l >> 3) & 3));
+#elif defined(DRYV_EXP_KIND_PLAIN)
+      return *(recF + (MREC_WORDS * mb_index(step + (l >> 5), (l >> 3) & 3) + 5u));
+#else
+      return wv::ld_sc1(recF + (MREC_WORDS * mb_index(step + (l >> 5), (l >> 3) & 3) + 5u));
+#endif
     };
     u32x4 cB0, cB1;
     int dcB;
@@ -1247,11 +1295,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     for (int s = 0; s < nSteps; s++) {
       const bool evenStep = (s & 1) == 0;
       if (evenStep) {
-        // the record checks FRONT makes (it also reports them), once per pair of steps: an unsupported record becomes
-        // kind 3 / qp 0 here, reconstructs as zero, and is only read field by field afterwards
-        dC = kN1;
-        const unsigned kd = dC & 0xffu;
-        if (kd > 2u || (!HAS_I8 && kd == 1u) || (dC >> 24) > 51u || ((dC >> 8) & 0xffu) > 3u || ((dC >> 16) & 0xffu) > 3u) dC = 3u;
+        dC = kN1;   // (checked by band_modes: an unsupported record reads as kind 3 / qp 0 and reconstructs as zero)
       }
       const int lane = wv::opaque(lane0);
       const int g = lane >> 4, i = lane & 15;                                            // write-out organisation: row g
@@ -1319,15 +1363,27 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         // chroma DC 2x2 (8.5.11, trans_chroma.rs:369-415) over the four block lanes of a plane, then the AC pass.
         // The LevelScale table is luma's (quirk Q3).
         const int qc = (int)wv::lds_u8(ldsBase + T_QPC + 52 * cpl + qpR);
-        const int qd = (qc * 43) >> 8, qm = qc - 6 * qd;
         int v = dcB;
         int o = xor1(v);
         v = (cblk & 1) ? o - v : v + o;
         o = xor2(v);
         v = (cblk & 2) ? o - v : v + o;
-        const int ls00 = (int)wv::lds_u16(ldsBase + T_LS4Z + 32 * qm);
-        const long long dcC = (((long long)v * ls00) * (1ll << qd)) >> 5;   // trans_chroma.rs:413
-        residual_pass<WIDE>(cB0, cB1, ldsBase, ldsBase + T_LS4Z + 32 * qm, qc, true, dcC, (int)wv::lds_u16(ldsBase + T_THR4 + 2 * qc), false, A.status, rB);
+        const u32x2 qq = wv::lds_u64(ldsBase + T_QP + 32 * qc + 16);   // LevelScale(0,0), qp / 6
+        // ((f * LS) << (qp/6)) >> 5   (trans_chroma.rs:413)
+        int dcC;
+        bool dcHuge;
+        long long dcWide = 0;
+        if (WIDE) {
+          dcWide = (((long long)v * (int)qq.x) * (1ll << qq.y)) >> 5;
+          dcHuge = dcWide > (1ll << 26) || dcWide < -(1ll << 26);
+          dcC = (int)dcWide;
+        } else {
+          // |f| < 2^(17 - qp/6) and LevelScale(0,0) < 2^13 keep the shifted product inside 32 bits (as for Intra16x16 DC)
+          const unsigned lim = 1u << (17u - qq.y);
+          dcHuge = (unsigned)(v + (int)lim - 1) > 2u * lim - 2u;
+          dcC = (int)((unsigned)(v * (int)qq.x) << qq.y) >> 5;
+        }
+        residual_pass<WIDE>(cB0, cB1, ldsBase, qc, true, dcC, dcHuge, dcWide, false, A.status, rB, []() {});
         if (wv::any(kindR == 3)) {
 #pragma unroll
           for (int k = 0; k < 8; k++) rB[k] = kindR == 3 ? 0u : rB[k];

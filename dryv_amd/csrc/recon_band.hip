@@ -44,6 +44,9 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5
   if (role == 1 && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
   if (role == 2 && DRYV_BAND_PRIO_CHROMA) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_CHROMA);
   if (role == 0 && DRYV_BAND_PRIO_FRONT) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_FRONT);
+#ifdef DRYV_BAND_ONLY_ROLE   // analysis only (tools/resource_usage.py): the registers one role needs when compiled alone
+  if (role != DRYV_BAND_ONLY_ROLE) return;
+#endif
   if (role == 1) band::band_back<HAS_I8>(P, A, ldsBase, ts);
   else if (role == 0) band::band_front<HAS_I8, WIDE>(P, A, ldsBase, ts);
   else band::band_chroma<HAS_I8, WIDE>(P, A, ldsBase, ts);

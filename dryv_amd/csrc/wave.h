@@ -73,6 +73,12 @@ WV void lds_st128(int a, u32x4 v) { *WV_LDS(u32x4, a) = v; }
 WV unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 WV unsigned sad4(unsigned w) { return __builtin_amdgcn_sad_u8(w, 0u, 0u); }
 WV int med3(int a, int lo, int hi) { return min(max(a, lo), hi); }
+// the same as one instruction for bounds the compiler cannot order (lo <= hi is the caller's business)
+WV int clamp3(int a, int lo, int hi) {
+  int d;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(lo), "v"(hi));
+  return d;
+}
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 // packed signed 16-bit add with saturation (v_pk_add_i16 clamp)
 WV unsigned pk_add_sat(unsigned a, unsigned b) {
@@ -286,6 +292,7 @@ WV unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
 }
 WV unsigned sad4(unsigned w) { return (w & 0xff) + ((w >> 8) & 0xff) + ((w >> 16) & 0xff) + (w >> 24); }
 WV int med3(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
+WV int clamp3(int a, int lo, int hi) { return med3(a, lo, hi); }
 WV int emu_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 WV unsigned pk_max(unsigned a, unsigned b) {
   const int16_t al = (int16_t)a, ah = (int16_t)(a >> 16), bl = (int16_t)b, bh = (int16_t)(b >> 16);
