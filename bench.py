@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — macroblocks/s of the MI355X reconstruction path on BASELINE.json's workload.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, launch_ranks below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -20,11 +20,41 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
-import dryv_amd
-from dryv_amd import shard, synth
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` typed as is (no torch.distributed.run around it): the parent starts N fresh child processes,
+    one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's JSON line and
+    exits non-zero if any rank fails. It runs before this process has made any GPU call (nothing here imports torch or the
+    library), and the children are new processes, never an exec of one that has touched the GPU."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rc != 0 for rc in rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        sys.stdout.write(out0)
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
 
 def kernel_source_sha():
     """sha256 (16 hex digits) over the sources of the kernel the bench measures: measured HBM traffic is only quoted
@@ -82,7 +112,46 @@ def cpu_baseline(fp, mbs, coeffs, n_frames, gpu_out, frame_bytes, sample_frames)
     return out
 
 
+def dry_run(args, world, rank):
+    """The launcher and the control plane without a GPU (tests/test_bench_launcher.py): every rank joins the process group
+    over gloo, receives the parameter block and its shard from rank 0, generates the shard's first frame on the host and
+    reports; rank 0 prints one JSON line with value null. Nothing is reconstructed and nothing is measured."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    cid, w, h, frames, t8, kw = synth.WORKLOADS[args.workload]
+    per_gpu = args.frames_per_gpu or frames
+    fp = dryv_amd.make_frame_params(w, h, transform_8x8=t8)
+    table = shard.partition_frames(per_gpu * world, world)
+    ctrl = torch.device("cpu")
+    fp, table = shard.broadcast_control(fp, table, ctrl, rank, world)
+    first, n_frames = table[rank]
+    per = fp.pic_width_in_mbs * fp.pic_height_in_mbs
+    mbs, coeffs = synth.generate(fp, synth.config(**kw), cid, first, 1)
+    checksum = int(np.bitwise_xor.reduce(coeffs.reshape(-1).view(np.uint16).astype(np.uint64))) ^ (first << 32)
+    reports = shard.gather_reports(n_frames, n_frames * per, checksum, ctrl, world)
+    if rank == 0:
+        print(json.dumps({"metric": "macroblocks/s (1080p all-intra)", "value": None, "unit": "macroblocks/s", "n_gpus": world,
+                          "dry_run": True, "scaling": "weak",
+                          "config": {"workload": args.workload, "frames_per_gpu": n_frames,
+                                     "shards": [[int(a), int(b)] for a, b in table],
+                                     "ranks_reporting": len(reports), "macroblocks_per_step": sum(r[1] for r in reports)}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    if "WORLD_SIZE" not in os.environ and pre.parse_known_args()[0].gpus > 1:
+        return launch_ranks(pre.parse_known_args()[0].gpus, sys.argv[1:])   # (before anything below touches the GPU)
+    global torch, dist, dryv_amd, shard, synth
+    import torch
+    import torch.distributed as dist
+    import dryv_amd
+    from dryv_amd import shard, synth
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -95,16 +164,18 @@ def main():
     ap.add_argument("--preroll-ms", type=float, default=40.0, help="untimed device pre-roll before the warm-up steps")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="wait on the host after every step (round 1/2 behaviour) instead of queueing the steps on the stream")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / control-plane rehearsal without a GPU: ranks over gloo, no reconstruction, value null")
     args = ap.parse_args()
+
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world   # (under torch.distributed.run the launcher's world size wins)
+    if args.dry_run:
+        return dry_run(args, world, rank)
     # One rank per GPU. (DRYV_BENCH_BACKEND=gloo is a rehearsal hook for boxes with fewer GPUs than ranks: the ranks
     # then share devices and the control plane runs over gloo on the host; the product path is RCCL.)
     backend = os.environ.get("DRYV_BENCH_BACKEND", "nccl")
@@ -261,4 +332,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

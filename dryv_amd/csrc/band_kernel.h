@@ -155,6 +155,13 @@ constexpr unsigned TASK_END = 0xFFFFFFFFu;
 #define DRYV_BAND_EXP_SKIP 0
 #endif
 #define EXP_SKIP(k) ((((DRYV_BAND_EXP_SKIP) >> (k)) & 1) != 0)
+// The opposite measurement, which does not let the compiler simplify anything around the phase: -DDRYV_BAND_EXP_DUP=k runs
+// phase k of the step TWICE (the phases are idempotent), so that the difference in SQ_INSTS_VALU is its dynamic count.
+#ifndef DRYV_BAND_EXP_DUP
+#define DRYV_BAND_EXP_DUP (-1)
+#endif
+#define EXP_REP(k) for (int rep_ = 0, nrep_ = (DRYV_BAND_EXP_DUP) == (k) ? wv::opaque(2) : 1; rep_ < nrep_; rep_++)
+#define EXP_DUP_IS(k) ((DRYV_BAND_EXP_DUP) == (k))
 
 // Diagnostic builds only. -DDRYV_BAND_PROFILE (tools/band_phases.py): per-wave cycle sums per phase of the step.
 // -DDRYV_BAND_TRACE (tools/band_trace.py): breadcrumbs only. Both write to a buffer of their own; the shipped library
@@ -738,7 +745,8 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
   if (lane < 4) wv::lds_st32(ts + S_CARRYM + 4 * lane, 0x02020202u);
   wv::wave_sync();
   // One iteration = 64 macroblocks of one row: batch after batch, the band's rows inside a batch (row g's neighbour B
-  // is the same lane one iteration earlier). The next iteration's records are requested before this one's arithmetic.
+  // is the same lane one iteration earlier). (No prefetch across iterations: the wave that runs this -- CHROMA, between
+  // two tasks -- is ahead of the luma waves, and the registers are worth more than the latency.)
   const int nR = G.nR, nIter = ((W + 63) >> 6) * nR;
   auto mb_of = [&](int it) -> unsigned {   // this lane's macroblock in iteration `it` (the last one of the row beyond it)
     const int xb = it / nR, gg = it - xb * nR;
@@ -748,8 +756,6 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
     const unsigned mbn = mb_of(it);
     return (G.hasAbove && it % nR == 0) ? wv::ld_sc1(recF + (size_t)MREC_WORDS * (mbn - (unsigned)W) + 7) : 0x02020202u;
   };
-  u32x4 dNext = wv::ld_u128_a2(mbsF + 16u * mb_of(0));
-  unsigned topNext = load_top(0);
   unsigned bottom = 0x02020202u;  // raw modes of the bottom grid row of the macroblock above (same lane, previous iteration)
 #pragma clang loop unroll(disable)
   for (int it = 0; it < nIter; it++) {
@@ -761,12 +767,8 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
       const int r = G.r0 + g;
       const bool rowTop = r > 0;  // (wave-uniform) macroblock B exists
       const unsigned mb = mb_of(it);
-      const u32x4 d = dNext;
-      const unsigned topM = g == 0 ? topNext : bottom;
-      if (it + 1 < nIter) {
-        dNext = wv::ld_u128_a2(mbsF + 16u * mb_of(it + 1));
-        topNext = load_top(it + 1);
-      }
+      const u32x4 d = wv::ld_u128_a2(mbsF + 16u * mb);
+      const unsigned topM = g == 0 ? load_top(it) : bottom;
       const unsigned carry = wv::lds_u32(ts + S_CARRYM + 4 * g);
       // the record checks of the step (an unsupported record reconstructs as zero and counts as DC for its neighbours)
       int kind = (int)(d.x & 0xffu);
@@ -1043,6 +1045,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       PH(1);  // record decode
       // ================= residuals ================================================================================
       unsigned rA[8];
+      EXP_REP(0)
       if (EXP_SKIP(0)) {
 #pragma unroll
         for (int k = 0; k < 8; k++) rA[k] = cA0.x;
@@ -1083,7 +1086,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         // pass below reads them again: such a stream requests them behind it)
         const u32x4 cC0 = cA0, cC1 = cA1;
         residual_pass<WIDE>(cC0, cC1, ldsBase, qp, kind == 2, dcY, kind == 2 && dcHuge, dcWide, HAS_I8 && kind == 1, A.status, rA,
-                            [&]() { if (!HAS_I8) load_coefs_luma(s + 1, kN1); });
+                            [&]() { if (!HAS_I8 && !EXP_DUP_IS(0)) load_coefs_luma(s + 1, kN1); });
         // Intra8x8 macroblocks: their lanes' rA becomes 16 residuals of one column per 8x8 block pass (residual8x8)
         if (HAS_I8 && wv::any(valid && kind == 1)) {
           unsigned r8[8];
@@ -1127,7 +1130,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         }
       }
       haveN = haveNext;
-      if (HAS_I8 || EXP_SKIP(0)) load_coefs_luma(s + 1, kN1);  // (otherwise: requested inside the residual pass)
+      if (HAS_I8 || EXP_SKIP(0) || EXP_DUP_IS(0)) load_coefs_luma(s + 1, kN1);  // (otherwise: requested inside the residual pass)
       PH(3);  // hand-off traffic, coefficient prefetch
 
       // ---- the step's record for BACK: residuals [blkIdx][y][x], table rows, kinds. The buffer is free once BACK has
@@ -1240,7 +1243,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     {
       unsigned* const myProgM = A.progM + (size_t)G.f * nBands + G.b;
       wv::setprio<DRYV_BAND_PRIO_MODES>();
-      band_modes<HAS_I8>(P, A, G, task, ts, mbsF, recF, myProgM - 1, myProgM);
+      EXP_REP(10) band_modes<HAS_I8>(P, A, G, task, ts, mbsF, recF, myProgM - 1, myProgM);
       wv::setprio<DRYV_BAND_PRIO_CHROMA>();
       if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_MODES, seq + 1);
     }
@@ -1383,7 +1386,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
           dcHuge = (unsigned)(v + (int)lim - 1) > 2u * lim - 2u;
           dcC = (int)((unsigned)(v * (int)qq.x) << qq.y) >> 5;
         }
-        residual_pass<WIDE>(cB0, cB1, ldsBase, qc, true, dcC, dcHuge, dcWide, false, A.status, rB, []() {});
+        EXP_REP(6) residual_pass<WIDE>(cB0, cB1, ldsBase, qc, true, dcC, dcHuge, dcWide, false, A.status, rB, []() {});
         if (wv::any(kindR == 3)) {
 #pragma unroll
           for (int k = 0; k < 8; k++) rB[k] = kindR == 3 ? 0u : rB[k];
@@ -1402,6 +1405,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       PH(2);  // chroma residuals, prefetch
 
       // ================= chroma: 8.3.4 (trans_chroma.rs:96-366), lane = (block half, row gc, plane, block) =======
+      EXP_REP(7)
       if (!EXP_SKIP(7)) {
         const unsigned dP = evenStep ? dEven : dOdd;
         const int kindC = (int)(dP & 0xffu), cmode = (int)((dP >> 16) & 0xffu);
@@ -1506,7 +1510,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       kN1 = (unsigned)wv::opaque((int)kN1);
       cB0.x = (unsigned)wv::opaque((int)cB0.x); cB1.x = (unsigned)wv::opaque((int)cB1.x); dcB = wv::opaque(dcB);
       // bottom chroma lines for the row below (ring) or the band below (write-through): lanes 0..1 of row g Cb, 2..3 Cr
-      {
+      EXP_REP(12) {
         unsigned v = 0;
         if (i < 4) v = wv::lds_u32(aBot + 8 * slot);
         if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(aRing + RINGC_ENT * (x & 3), v);
@@ -1523,6 +1527,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       wv::wave_sync();
       // flush the staged rows: every NSC-th macroblock, or at the end of a row: 8 * NSC contiguous bytes per pixel row.
       // The bottom lines of a band that has a band below were already written through.
+      EXP_REP(8)
       if (!EXP_SKIP(8) && wv::any(valid && (slot == NSC - 1 || x == W - 1))) {
         constexpr int LR = 8 * NSC;  // lanes per macroblock row: 2 planes x 8 pixel rows x NSC / 2 segments of 16 bytes
 #pragma unroll
@@ -1641,6 +1646,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     PH(1);  // top border
 
       // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
+      EXP_REP(3)
       if (!EXP_SKIP(3) && wv::any(valid && kind >= 2)) {
         const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
         const unsigned lw = wv::lds_u32(ts + S_LEFTY + 16 * g + 4 * zby);
@@ -1738,6 +1744,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       // lane = (row g, block half ch, pixel pair cp). Rounds with two blocks per macroblock (2..7): pixels
       // (2 * (cp & 1) + {0, 1}, cp >> 1) of block (bx0, by0) for ch = 0, of block (bx0 - 2, by0 + 1) for ch = 1. Rounds with
       // one block (0, 1, 8, 9): all sixteen lanes work on it, one pixel each: (2 * (cp & 1) + ch, cp >> 1).
+      EXP_REP(4)
       if (anyI4) {
         const bool mine = valid && kind == 0;
         const int px = 2 * (cp & 1), py = cp >> 1;
@@ -1934,7 +1941,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       PH(4);  // Intra4x4 chain
 
       // ================= luma write-out ============================================================================
-      {
+      EXP_REP(11) {
         // bottom line for the row below (ring) or the band below (write-through): lanes 0..3 of row g
         unsigned v = 0;
         if (i < 4) v = wv::lds_u32(tile + TILE_STRIDE * 16 + 8 + 16 * slot + 4 * i);
@@ -1953,6 +1960,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       wv::wave_sync();
       // flush the staged rows: every NSY-th macroblock, or at the end of a row: 16 * NSY contiguous bytes per pixel row.
       // The bottom line of a band that has a band below was already written through.
+      EXP_REP(5)
       if (!EXP_SKIP(5) && wv::any(valid && ((x & (NSY - 1)) == NSY - 1 || x == W - 1))) {
         constexpr int LR = 16 * NSY;  // lanes per macroblock row: 16 pixel rows x NSY segments of 16 bytes
 #pragma unroll

@@ -157,7 +157,7 @@ WV void wait_vm(int n) {
 WV void sleep_short() { __builtin_amdgcn_s_sleep(DRYV_BAND_SLEEP); }
 WV void sleep_long() { __builtin_amdgcn_s_sleep(32); }
 #ifndef DRYV_TEAM_SLEEP
-#define DRYV_TEAM_SLEEP 1
+#define DRYV_TEAM_SLEEP 4
 #endif
 WV void sleep_team() { __builtin_amdgcn_s_sleep(DRYV_TEAM_SLEEP); }  // between two polls of the partner wave's LDS flag
 WV void compiler_fence() { asm volatile("" ::: "memory"); }
