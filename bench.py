@@ -61,7 +61,7 @@ def kernel_source_sha():
     for the build it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("band_kernel.h", "recon_band.hip", "wave.h", "recon_kernel.hip"):
+    for f in ("band_kernel.h", "recon_band.hip", "wave.h"):
         with open(os.path.join(ROOT, "dryv_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -276,8 +276,7 @@ def main():
         all_verified, kernel_ms_max = verified, float(vt[1].item())
     if not all_verified:
         sys.exit("bench.py: a rank's shard differs from the oracle")
-    sel = os.environ.get("DRYV_RECON_KERNEL", "")   # default: band kernel, except streams with the 8x8 transform
-    kernel_name = "band_kernel" if (sel == "band" or (sel != "row" and not t8)) else "recon_kernel"
+    kernel_name = "band_kernel"
 
     if rank == 0:
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3

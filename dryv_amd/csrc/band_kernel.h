@@ -90,15 +90,17 @@ constexpr int TILE_BYTES = 704;  // 17 rows x 40 + 8 (row y = -1 of slot 1 reach
 constexpr int NP = NSY / 2;
 constexpr int CW = 8 * NSC;      // chroma staging: bytes per pixel row
 // FRONT -> BACK, double-buffered by the parity of the team's global step count
-constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [4 * by + bx][y][x]
-constexpr int S_MSEQ = 4096;     // u8  [2][4][2][12]       8 x the Intra4x4 table row per chain step and block half (always a multiple of 8)
-constexpr int S_INFO = 4288;     // u32 [2][8]              kinds of the 4 macroblocks, Intra16x16 modes, task, step, parity, chain rounds with a DC block
-constexpr int S_FLAGS = 4352;    // u32 ready[2], free[2] (global step count + 1 of the record in / consumed from the
+constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [4 * by + bx][y][x]; a row group every RES_ROW bytes (512 + 32:
+constexpr int RES_ROW = 544;     //     8 banks behind the previous one: the rows of a band address their records alike in every
+constexpr int RES_BUF = 4 * RES_ROW;          //     instruction), a buffer every RES_BUF
+constexpr int S_MSEQ = S_RES + 2 * RES_BUF;   // u8  [2][4][2][12]  8 x the Intra4x4 table row per chain step and block half (always a multiple of 8)
+constexpr int S_INFO = S_MSEQ + 192;          // u32 [2][8]         kinds of the 4 macroblocks, Intra16x16 modes, task, step, parity, chain rounds with a DC block
+constexpr int S_FLAGS = S_INFO + 64;          // u32 ready[2], free[2] (global step count + 1 of the record in / consumed from the
                                  //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks),
                                  //     modesDone (CHROMA -> FRONT: tasks whose mode pre-pass is through)
 constexpr int F_READY = 0, F_FREE = 8, F_TASKS = 16, F_HEAD = 32, F_TAILC = 36, F_MODES = 40;
 // BACK (+ FRONT writes row 0 of the luma ring: lines fetched from the band above)
-constexpr int S_TILE = 4416;     // u8  [4][NP][TILE_BYTES]  luma: tile (x >> 1) % NP, row j = y + 1, column 8 + 16 * (x & 1) + xr
+constexpr int S_TILE = S_FLAGS + 64;  // u8  [4][NP][TILE_BYTES]  luma: tile (x >> 1) % NP, row j = y + 1, column 8 + 16 * (x & 1) + xr
 constexpr int S_RINGY = S_TILE + 4 * NP * TILE_BYTES;  // bottom luma lines of the row above: row 0 [2][8][16], rows 1..3 [4][16]
 constexpr int S_LEFTY = S_RINGY + 448;            // u8 [4][16]     column 15 of the macroblock to the left
 // CHROMA
@@ -111,11 +113,11 @@ constexpr int S_CARRYM = S_LEFTC + 64;            // u32 [4]     mode pre-pass: 
 constexpr int S_BYTES = (S_CARRYM + 64 + 63) & ~63;
 // builds that serve the 8x8 transform (HAS_I8) append, per team:
 constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order
-constexpr int S_G8 = S_C8 + 2048;      // T   [4][2 blk8][8][8]  FRONT: row-pass output of the two blocks of a pass (T up to 8 bytes)
-constexpr int S_E8 = S_G8 + 4096;      // [4][128]  BACK: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16,
+constexpr int S_E8 = S_C8 + 2048;      // [4][128]  BACK: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16,
                                        //           then E1 as bytes (L7..L0, TL at 100..108, T0..T15 at 112..127)
-constexpr int S_BYTES_I8 = S_E8 + 512;
-constexpr int team_bytes(bool hasI8) { return hasI8 ? S_BYTES_I8 : S_BYTES; }
+constexpr int S_G8 = S_E8 + 512;       // T   [4][2 blk8][8][8]  FRONT: row-pass output of the two blocks of a pass (T: 4 bytes; 8 in the
+                                       //           WIDE build, whose teams are that much larger)
+constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 2048) : S_BYTES; }
 static_assert(S_CARRYM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
@@ -909,7 +911,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
   // the most arithmetic per register (kept behind an optimisation barrier)
   const int hi4 = lane0 & 15, hzbx = ((hi4 >> 1) & 2) | (hi4 & 1), hzby = ((hi4 >> 2) & 2) | ((hi4 >> 1) & 1);
   const int hPermDc = wv::opaque((lane0 & 48) + zidx((0x1320 >> (4 * hzbx)) & 3, (0x1320 >> (4 * hzby)) & 3));  // Intra16x16 DC: source lane of the last stage
-  const int hResOff = wv::opaque(512 * (lane0 >> 4) + 32 * (4 * hzby + hzbx));                                   // this lane's block in the residual record
+  const int hResOff = wv::opaque(RES_ROW * (lane0 >> 4) + 32 * (4 * hzby + hzbx));                                   // this lane's block in the residual record
 
   // Claims the task of sequence number q of this team and hands it to CHROMA (a ring of four task numbers).
   // Every lane takes part in the claim (lane 0 adds 1, the others 0) and in the progress-word loads further down:
@@ -1141,7 +1143,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         // word: element (row k, column j) goes to 4x4 block (bx, by) = (2 * (b8 & 1) + (j >> 2), 2 * (b8 >> 1) + (k >> 2)),
         // position (k & 3, j & 3)
         const int j = i & 7;
-        const int dst = ts + S_RES + 2048 * buf + 512 * g + 64 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
+        const int dst = ts + S_RES + RES_BUF * buf + RES_ROW * g + 64 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
 #pragma unroll
         for (int pk = 0; pk < 16; pk++) {
           const int p = pk >> 3, k = pk & 7;
@@ -1149,7 +1151,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
           wv::lds_st16(dst + 256 * p + 128 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
         }
       } else {
-        const int dst = ts + S_RES + 2048 * buf + hResOff;
+        const int dst = ts + S_RES + RES_BUF * buf + hResOff;
         wv::lds_st128(dst, u32x4{rA[0], rA[1], rA[2], rA[3]});
         wv::lds_st128(dst + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
       }
@@ -1615,7 +1617,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     }
     const int r0 = G.r0, nR = G.nR, gl = G.gl;
     const bool hasBelow = G.hasBelow;
-    const int resBuf = ts + S_RES + 2048 * buf;
+    const int resBuf = ts + S_RES + RES_BUF * buf;
 
     const int lane = lane0;  // (BACK has registers to spare: whatever depends on the lane alone is computed once, outside the loop)
     const int g = lane >> 4, i = lane & 15;
@@ -1717,7 +1719,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 #pragma unroll
             for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
           }
-          const int rsrc = resBuf + 512 * g + 32 * (4 * zby + zbx);
+          const int rsrc = resBuf + RES_ROW * g + 32 * (4 * zby + zbx);
           const u32x4 ra = wv::lds_u128(rsrc), rb = wv::lds_u128(rsrc + 16);
           const unsigned rA[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
           const int dst = tile + TILE_STRIDE * (4 * zby + 1) + 8 + 16 * slot + 4 * zbx;
@@ -1755,8 +1757,8 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         const int orgS = tile + 8 + 16 * slot - 1;                  // (block origin - one row - one column) of block (0, 0)
         const int orgB = orgS + (ch ? 4 * TILE_STRIDE - 8 : 0);     // ... of block (0, 0) / (-2, 1)
         const int stB = orgB + TILE_STRIDE * (py + 1) + 1 + px, stS = orgS + TILE_STRIDE * (py + 1) + 1 + px + ch;
-        const int resS = resBuf + 512 * g + 4 * cp + 2 * ch;        // residuals [4 * by + bx][y][x]: this lane's one pixel
-        const int resB = resBuf + 512 * g + 4 * cp + (ch ? 64 : 0); // ... this lane's pixel pair
+        const int resS = resBuf + RES_ROW * g + 4 * cp + 2 * ch;        // residuals [4 * by + bx][y][x]: this lane's one pixel
+        const int resB = resBuf + RES_ROW * g + 4 * cp + (ch ? 64 : 0); // ... this lane's pixel pair
         const int entB = ldsBase + T_T4E + 96 * cp, entS = entB + 4 * ch;
         const bool nchOrA = ch == 0 || mbA;
         // the table rows of all ten steps (they do not depend on pixels): this lane's block half, and the first half's
@@ -1866,6 +1868,16 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         const unsigned modes4 = wv::lds_u32(ts + S_MSEQ + 96 * buf + 24 * g);
         const bool mbC = mbB && (x + 1 < P.W);
         const int py = i >> 1, x0 = 4 * (i & 1);
+        // the four blocks' table entries (mode, pixel) and residuals depend on nothing the chain below produces: requested
+        // up front, so that a block's serial part is two LDS round trips (edge samples, filtered edge), not three
+        unsigned te4s[4];
+        u32x2 rrs[4];
+#pragma unroll
+        for (int b8 = 0; b8 < 4; b8++) {
+          const int m8 = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
+          te4s[b8] = wv::lds_u32(ldsBase + T_T8 + 64 * m8 + 8 * py + x0);
+          rrs[b8] = wv::lds_u64(resBuf + RES_ROW * g + 32 * (4 * (2 * (b8 >> 1) + (py >> 2)) + 2 * (b8 & 1) + (x0 >> 2)) + 8 * (py & 3));
+        }
 #pragma unroll
         for (int b8 = 0; b8 < 4; b8++) {
           const int bx = b8 & 1, by = b8 >> 1;
@@ -1909,7 +1921,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           }
           wv::wave_sync();
           // four pixels of row py: x0 .. x0 + 3
-          const unsigned te4 = wv::lds_u32(ldsBase + T_T8 + 64 * mode + 8 * py + x0);
+          const unsigned te4 = te4s[b8];
           unsigned pr[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
@@ -1928,7 +1940,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
               pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
             }
           }
-          const u32x2 rr = wv::lds_u64(resBuf + 512 * g + 32 * (4 * (2 * by + (py >> 2)) + 2 * bx + (x0 >> 2)) + 8 * (py & 3));
+          const u32x2 rr = rrs[b8];
           const unsigned o = recon_row(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16), rr.x, rr.y);
           if (mine) wv::lds_st32(org8 + TILE_STRIDE * (py + 1) + x0, o);
           wv::wave_sync();

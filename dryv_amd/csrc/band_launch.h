@@ -1,0 +1,22 @@
+// band_launch.h — launch interface between the host API (recon_api.hip) and the gfx950 band kernel (recon_band.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dryv_recon.h"
+#include "kparams.h"
+
+namespace dryv {
+
+// Band kernel (band_kernel.h): a team of three waves per 4-row band; grid = workgroups of band_teams_per_block() teams.
+size_t band_lds_bytes(bool hasI8, bool wide, int teams);
+int band_teams_per_block(bool hasI8, bool wide);
+int band_blocks_per_cu(bool hasI8, bool wide);
+size_t band_workspace_bytes(const KParams& P);
+size_t band_reset_bytes(const KParams& P);      // leading bytes of the workspace a launch needs zeroed
+size_t band_profile_offset(const KParams& P);   // diagnostic builds: per-wave phase sums / breadcrumbs behind the workspace
+hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
+                       void* d_workspace, int grid, bool wide, hipStream_t stream);
+
+}  // namespace dryv

@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "recon_kernel.h"
+#include "band_launch.h"
 #include "recon_params.h"
 #include "output_pack.h"
 #include "deblock_launch.h"
@@ -52,7 +52,7 @@ struct dryv_recon_ctx {
   size_t cap_work = 0;
   int num_cus = 256;
   int grid_override = 0;
-  int kernel_sel = -1;  // DRYV_RECON_KERNEL: 0 row kernel, 1 band kernel, -1 default
+  bool force_wide = false;  // DRYV_RECON_FORCE_WIDE (test hook): every launch with the WIDE build (64-bit residual arithmetic)
   // the launch in flight, kept so that a batch the fast band kernel flagged (status bit 1: a block beyond int32)
   // can be run again with the wide build before its status is reported
   KParams last_P;
@@ -97,7 +97,7 @@ int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
 }
 
 size_t workspace_bytes(const KParams& P) {
-  size_t b = std::max(dryv::recon_workspace_bytes(P.W, P.H, P.n_frames), dryv::band_workspace_bytes(P));
+  size_t b = dryv::band_workspace_bytes(P);
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE) || defined(DRYV_BAND_TIMELINE)
   b = dryv::band_profile_offset(P) + (size_t)65536 * 16 * 8 + (size_t)65536 * 32 * 2;  /* phases, trace, timeline */
 #endif
@@ -115,7 +115,7 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   hipError_t e;
   const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
   const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, wide);
-  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, wide);
   if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
   if (grid < 1) grid = 1;
   e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream);
@@ -142,24 +142,14 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
 // chunks (it is cleared once per submit), no events.
 int launch_chunk(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv) {
   hipError_t e;
-  const bool band = ctx->kernel_sel == 1 || (ctx->kernel_sel < 0 && !P.transform8x8);
-  ctx->last_band = band;
-  if (band) {
-    const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
-    const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, false);
-    long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu();
-    grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
-    if ((e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
-    e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, ctx->stream);
-    return e == hipSuccess ? DRYV_OK : fail(ctx, e, "band_kernel launch");
-  }
-  const int bpb = dryv::recon_bands_per_block();
-  const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
-  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::recon_blocks_per_cu();
-  grid = std::max(1ll, std::min(grid, (total_bands + bpb - 1) / bpb));
-  if ((e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
-  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
-  return e == hipSuccess ? DRYV_OK : fail(ctx, e, "recon_kernel launch");
+  ctx->last_band = true;
+  const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
+  const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, false);
+  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, false);
+  grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
+  if ((e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, ctx->stream);
+  return e == hipSuccess ? DRYV_OK : fail(ctx, e, "band_kernel launch");
 }
 
 // Waits for the launch in flight. A batch the fast band kernel flagged as needing 64-bit arithmetic is run again with
@@ -171,7 +161,7 @@ int finish(dryv_recon_ctx* ctx) {
     ctx->piped = false;
     if ((e = hipStreamSynchronize(ctx->s_out)) != hipSuccess) return fail(ctx, e, "hipStreamSynchronize(copy-out)");
     if (*ctx->h_status & 2u) {
-      // a block beyond int32 (flagged by either kernel): the whole batch again, unpipelined, with the band kernel's wide
+      // a block beyond int32: the whole batch again, unpipelined, with the band kernel's wide
       // build (never for a conformant stream)
       ctx->wide_reruns++;
       ctx->last_band = true;
@@ -218,33 +208,14 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   hipError_t e = hipSuccess;
   if (reset_status) e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
-  // Persistent grid: 32 waves per CU (8 per SIMD at 64 VGPRs); each band slot of a workgroup keeps claiming 4-row
-  // bands until none are left, so a smaller grid is merely slower and never incorrect.
-  const bool band = ctx->kernel_sel == 1 || (ctx->kernel_sel < 0 && !P.transform8x8);
+  // Persistent grid: every team keeps claiming 4-row bands until none are left, so a smaller grid is merely slower and
+  // never incorrect.
   ctx->last_P = P;
   ctx->last_mbs = d_mbs;
   ctx->last_coeffs = d_coeffs;
   ctx->last_yuv = d_yuv;
-  ctx->last_band = band;
-  if (band) return launch_band(ctx, P, d_mbs, d_coeffs, d_yuv, false);
-  const int bpb = dryv::recon_bands_per_block();
-  const long long total_bands = (long long)P.n_frames * ((P.H + 3) / 4);
-  long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::recon_blocks_per_cu();
-  if (grid > (total_bands + bpb - 1) / bpb) grid = (total_bands + bpb - 1) / bpb;
-  if (grid < 1) grid = 1;
-  e = dryv::recon_reset_workspace(P, ctx->d_work, (int)grid, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
-  next_events(ctx);
-  e = hipEventRecord(ctx->ev_start, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = dryv::recon_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "recon_kernel launch");
-  e = hipEventRecord(ctx->ev_stop, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipMemcpyAsync(status)");
-  ctx->timed = true;
-  return DRYV_OK;
+  ctx->last_band = true;
+  return launch_band(ctx, P, d_mbs, d_coeffs, d_yuv, ctx->force_wide);
 }
 
 }  // namespace
@@ -294,7 +265,7 @@ int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
       ctx->num_cus = prop.multiProcessorCount;
   }
   if (const char* s = getenv("DRYV_RECON_GRID")) ctx->grid_override = atoi(s);
-  if (const char* s = getenv("DRYV_RECON_KERNEL")) ctx->kernel_sel = strcmp(s, "band") == 0 ? 1 : strcmp(s, "row") == 0 ? 0 : -1;
+  if (const char* s = getenv("DRYV_RECON_FORCE_WIDE")) ctx->force_wide = atoi(s) != 0;
   *out = ctx;
   return DRYV_OK;
 }
@@ -647,18 +618,6 @@ const char* dryv_recon_strerror(int status) {
 }
 
 const char* dryv_recon_last_device_error(dryv_recon_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
-
-#ifdef DRYV_PHASE_PROFILE
-/* diagnostic build only: copies the per-wave phase cycle sums of the last launch (n_waves x 10 u64) */
-int dryv_recon_debug_phases(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uint32_t n_frames, int n_waves,
-                            unsigned long long* out) {
-  if (!ctx || !fp || !out || n_waves > 65536) return DRYV_E_INVALID;  /* rows of the timeline follow at slot 16384 */
-  const size_t prog = (((size_t)n_frames * fp->pic_height_in_mbs * 4) + 255) & ~(size_t)255;
-  const size_t off = ((256 + prog + (size_t)n_frames * fp->pic_width_in_mbs * fp->pic_height_in_mbs * 4) + 255) & ~(size_t)255;
-  hipError_t e = hipMemcpy(out, (unsigned char*)ctx->d_work + off, (size_t)n_waves * 80, hipMemcpyDeviceToHost);
-  return e == hipSuccess ? DRYV_OK : DRYV_E_DEVICE;
-}
-#endif
 
 #if defined(DRYV_BAND_TIMELINE)
 /* diagnostic build only: per band task of the last launch 4 x u64 (claim, BACK's first step, BACK's last step: 100 MHz

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "band_kernel.h"
-#include "recon_kernel.h"
+#include "band_launch.h"
 
 namespace dryv {
 
@@ -13,11 +13,17 @@ namespace dryv {
 #ifndef DRYV_BAND_WPS
 #define DRYV_BAND_WPS 6   // waves per SIMD the fast build is compiled for (<= 80 VGPRs)
 #endif
+#ifndef DRYV_BAND_WPS_I8
+#define DRYV_BAND_WPS_I8 5   // ... the build for streams with the 8x8 transform (<= 96 VGPRs)
+#endif
 #ifndef DRYV_BAND_WGS_PER_CU
 #define DRYV_BAND_WGS_PER_CU 2
 #endif
+#ifndef DRYV_BAND_WGS_PER_CU_I8
+#define DRYV_BAND_WGS_PER_CU_I8 5
+#endif
 template <bool HAS_I8, bool WIDE>
-__global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
+__global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? DRYV_BAND_WPS_I8 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds[];
   const int ldsBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   constexpr int tEnd = HAS_I8 ? band::T_END_I8 : band::T_END;
@@ -27,14 +33,14 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5
     // the teams' flag words (16), and the table-row bytes of the block chain (48 words): some are never written (the
     // second block half has no block in four of the ten rounds) and must still be offsets of table rows
     const int q = (int)(threadIdx.x & 63);
-    const int tsq = ldsBase + tEnd + (int)(threadIdx.x >> 6) * band::team_bytes(HAS_I8);
+    const int tsq = ldsBase + tEnd + (int)(threadIdx.x >> 6) * band::team_bytes(HAS_I8, WIDE);
     wv::lds_st32(q < 16 ? tsq + band::S_FLAGS + 4 * q : tsq + band::S_MSEQ + 4 * (q - 16), 0u);
   }
   __syncthreads();  // the only workgroup-level synchronisation: the teams are independent from here on
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // consecutive waves of a workgroup go to different SIMDs: a team's three waves never share one
   const int team = wave / band::WAVES_PER_TEAM, role = wave - team * band::WAVES_PER_TEAM;
-  const int ts = ldsBase + tEnd + team * band::team_bytes(HAS_I8);
+  const int ts = ldsBase + tEnd + team * band::team_bytes(HAS_I8, WIDE);
   // Wave priority by role (s_setprio: the SIMD's arbiter prefers the higher one when several waves can issue). FRONT is a
   // producer that runs up to two steps ahead of the other two; BACK is the wave on a band's critical path, and CHROMA's
   // bottom lines are what the band below's CHROMA waits for: the two consumers go first. Measured on the 300-picture
@@ -55,10 +61,16 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? 5
 #ifndef DRYV_BAND_LDS_PAD
 #define DRYV_BAND_LDS_PAD 0   // (tuning: extra LDS per workgroup, to cap the workgroups a CU accepts)
 #endif
-size_t band_lds_bytes(bool hasI8, int teams) { return (size_t)(hasI8 ? band::T_END_I8 : band::T_END) + (size_t)teams * band::team_bytes(hasI8) + DRYV_BAND_LDS_PAD; }
-// The builds that need more registers (8x8 transform: 96 VGPRs; wide: up to 128) run three teams per workgroup at most.
-int band_teams_per_block(bool hasI8, bool wide) { return (hasI8 || wide) ? (band::TEAMS_PER_WG < 3 ? band::TEAMS_PER_WG : 3) : band::TEAMS_PER_WG; }
-int band_blocks_per_cu() { return DRYV_BAND_WGS_PER_CU; }
+size_t band_lds_bytes(bool hasI8, bool wide, int teams) { return (size_t)(hasI8 ? band::T_END_I8 : band::T_END) + (size_t)teams * band::team_bytes(hasI8, wide) + DRYV_BAND_LDS_PAD; }
+// Workgroup geometry per build (tools/ab_inproc.py with -DDRYV_BAND_TEAMS / -DDRYV_BAND_WGS_PER_CU variants):
+//   * fast build, no 8x8 transform (80 VGPRs): 4 teams x 2 workgroups per CU; 1 x 8 measures the same, 2 x 4, 3 x 2 and
+//     1 x 7 are 3 ... 13 % slower.
+//   * fast build with the 8x8 transform (96 VGPRs, 5 waves per SIMD; more LDS per team): ONE team per workgroup, five per
+//     CU. Three-team workgroups left only one of them resident on a CU: 4.21 ms for the 100 x 4K batch against 3.59
+//     (2 teams) and 3.05 (1 team, 5 or 6 workgroups per CU).
+//   * wide builds (re-run of a flagged batch only; up to 128 VGPRs): one team per workgroup, four per CU.
+int band_teams_per_block(bool hasI8, bool wide) { return (hasI8 || wide) ? 1 : band::TEAMS_PER_WG; }
+int band_blocks_per_cu(bool hasI8, bool wide) { return wide ? 4 : hasI8 ? DRYV_BAND_WGS_PER_CU_I8 : DRYV_BAND_WGS_PER_CU; }
 
 // Workspace: [task counter | pad to 256][luma | chroma | modes progress words | pad to 256][mode records, 32 bytes per macroblock]
 // [diagnostics]
@@ -91,7 +103,7 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
 #endif
   const bool i8 = P.transform8x8 != 0;
   const int teams = band_teams_per_block(i8, wide);
-  const size_t ldsBytes = band_lds_bytes(i8, teams);
+  const size_t ldsBytes = band_lds_bytes(i8, wide, teams);
   const dim3 g(grid), b(64 * band::WAVES_PER_TEAM * teams);
   if (ldsBytes > 65536) {  // (build variants with wide staging: beyond the default dynamic LDS limit)
     const void* fn = i8 ? (wide ? (const void*)band_kernel<true, true> : (const void*)band_kernel<true, false>)

@@ -17,6 +17,7 @@
 #include <memory>
 #include <vector>
 
+#include "wave_emu.h"
 #include "../../dryv_amd/csrc/band_kernel.h"
 #include "../../dryv_amd/csrc/recon_params.h"
 
@@ -140,7 +141,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
     g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, prog.data() + (size_t)2 * n_frames * nBands, modes.data(), &counter, nullptr, 0};
     wv::g_body = body;
     std::vector<std::unique_ptr<wv::Wave>> waves;
-    const int teamBytes = dryv::band::team_bytes(g_P.transform8x8 != 0);
+    const int teamBytes = dryv::band::team_bytes(g_P.transform8x8 != 0, true);   // (one size for both passes: the wide build's)
     const int ldsBytes = (g_P.transform8x8 ? dryv::band::T_END_I8 : dryv::band::T_END) + teamBytes;
     std::vector<std::vector<uint8_t>> teamLds(n_teams, std::vector<uint8_t>(ldsBytes, 0xA5));
     for (int w = 0; w < n_waves; w++) {

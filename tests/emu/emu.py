@@ -15,7 +15,7 @@ def build(force=False, defs=()):
     """defs: extra -D flags (the kernel's build-time variants, e.g. staging widths); one library per set."""
     SO = os.path.join(HERE, "libdryv_emu%s.so" % "".join("_" + d.replace("-D", "").replace("=", "") for d in defs))
     csrc = os.path.join(HERE, "..", "..", "dryv_amd", "csrc")
-    deps = [os.path.join(HERE, "band_emu.cpp")] + [os.path.join(csrc, f) for f in
+    deps = [os.path.join(HERE, "band_emu.cpp"), os.path.join(HERE, "wave_emu.h")] + [os.path.join(csrc, f) for f in
                                                     ("band_kernel.h", "wave.h", "kparams.h", "recon_params.h", "deblock_kernel.h",
                                                      "deblock_kernel_params.h", "deblock_params.h")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):

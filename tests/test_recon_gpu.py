@@ -381,9 +381,11 @@ def test_full_int16_range_every_qp(recon_ctx, qp_range):
         assert_parity(recon_ctx, fp, 3, mbs, co)
 
 
-def test_row_and_band_kernels_agree():
-    """The two kernels in the library (band kernel: default without the 8x8 transform; row kernel: default with it; each
-    serves both) on the same batches, with and without Intra8x8, each forced through DRYV_RECON_KERNEL in a child process."""
+def test_fast_and_wide_builds_agree():
+    """The two builds of the band kernel -- the fast one (int32 / packed 16-bit residual arithmetic; flags what it cannot do)
+    and the WIDE one (64-bit fallback: what the library re-runs a flagged batch with) -- on the same ordinary batches, with
+    and without the 8x8 transform. The WIDE build is forced through DRYV_RECON_FORCE_WIDE (a test hook) in a child
+    process; the digests over all pictures must be equal."""
     import subprocess
     import sys
     code = (
@@ -401,12 +403,12 @@ def test_row_and_band_kernels_agree():
         "    h.update(ctx.reconstruct(fp, frames, mbs, co).tobytes())\n"
         "print('digest', h.hexdigest())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = {}
-    for kern in ("row", "band"):
-        env = dict(os.environ, DRYV_RECON_KERNEL=kern)
+    for wide in ("0", "1"):
+        env = dict(os.environ, DRYV_RECON_FORCE_WIDE=wide)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "digest" in r.stdout, (kern, r.stdout[-500:], r.stderr[-3000:])
-        out[kern] = r.stdout.split("digest")[1].strip()
-    assert out["row"] == out["band"]
+        assert r.returncode == 0 and "digest" in r.stdout, (wide, r.stdout[-500:], r.stderr[-3000:])
+        out[wide] = r.stdout.split("digest")[1].strip()
+    assert out["0"] == out["1"]
 
 
 def test_full_batch_properties_c3(recon_ctx):

@@ -20,11 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--burst", type=int, default=10)
-    ap.add_argument("--env", default="", help="NAME=VALUE exported before the contexts are created")
     a = ap.parse_args()
-    if a.env:
-        k, v = a.env.split("=", 1)
-        os.environ[k] = v
     fp, mbs, co, n = synth.workload(a.workload, n_frames=a.frames)
     d_m = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda()
     d_c = torch.from_numpy(co).cuda()

@@ -28,16 +28,20 @@ PHASES = {
 
 
 def main():
-    frame_list = [int(a) for a in sys.argv[1:]] or [1, 300]
+    wl = "C2_1080p_intra_4x4"
+    args = sys.argv[1:]
+    if args and args[0].startswith("C"):
+        wl, args = args[0], args[1:]
+    frame_list = [int(a) for a in args] or [1, 300]
     so = os.path.join(_build.LIB, "libdryv_recon_bprof.so")
-    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
+    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
     subprocess.check_call([_build.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-DDRYV_BAND_PROFILE", "-o", so] + srcs)
     import torch
     lib = abi.load_library(so)
     lib.dryv_recon_debug_band_phases.restype = C.c_int
     for frames in frame_list:
-        fp, mbs, co, n = synth.workload("C2_1080p_intra_4x4", n_frames=frames)
+        fp, mbs, co, n = synth.workload(wl, n_frames=frames)
         d_m = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda()
         d_c = torch.from_numpy(co).cuda()
         d_o = torch.zeros(mbs.size * 384, dtype=torch.uint8, device="cuda")
@@ -49,12 +53,12 @@ def main():
             assert lib.dryv_recon_sync(h) == 0
         ms = C.c_float()
         lib.dryv_recon_last_kernel_ms(h, C.byref(ms))
-        tasks = n * 17
+        tasks = n * ((fp.pic_height_in_mbs + 3) // 4)
         wpw = 3 * lib.dryv_recon_debug_band_teams() if hasattr(lib, "dryv_recon_debug_band_teams") else 9
         n_waves = 256 * 8 * 12
         out = np.zeros((n_waves, 16), dtype=np.uint64)
         assert lib.dryv_recon_debug_band_phases(h, C.c_int(n_waves), out.ctypes.data_as(C.c_void_p)) == 0
-        steps = tasks * 126.0
+        steps = tasks * (fp.pic_width_in_mbs + 6.0)
         print("== %d frames: instrumented kernel %.3f ms, %d band tasks" % (frames, ms.value, tasks))
         wave = np.arange(n_waves)
         for ri, role in enumerate(ROLES):

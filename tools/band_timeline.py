@@ -22,7 +22,7 @@ def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     flags = sys.argv[2:]
     so = os.path.join(_build.LIB, "libdryv_recon_btl.so")
-    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_kernel.hip", "recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
+    srcs = [os.path.join(_build.CSRC, f) for f in ("recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
     subprocess.check_call([_build.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w",
                            "-DDRYV_BAND_TIMELINE", "-o", so] + flags + srcs)
     import torch

@@ -5,7 +5,7 @@ mkdir -p $R/gpurun_out/tv
 for v in "$@"; do
   name=$(echo "$v" | tr -c 'A-Za-z0-9=\n' '_')
   so=$R/dryv_amd/lib/libdryv_recon_var.so
-  (cd $R && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w $v -o $so dryv_amd/csrc/recon_kernel.hip dryv_amd/csrc/recon_band.hip dryv_amd/csrc/output_pack.hip dryv_amd/csrc/deblock.hip dryv_amd/csrc/recon_api.hip) || exit 1
+  (cd $R && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w $v -o $so dryv_amd/csrc/recon_band.hip dryv_amd/csrc/output_pack.hip dryv_amd/csrc/deblock.hip dryv_amd/csrc/recon_api.hip) || exit 1
   cd /tmp && export TMPDIR=/tmp
   for c in FETCH_SIZE WRITE_SIZE; do
     DRYV_RECON_LIB=$so timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/tv/${name}_$c -- python3 $R/bench.py --steps 3 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-verify > $R/gpurun_out/tv/${name}_$c.log 2>&1 || echo "$c failed"

@@ -4,7 +4,6 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p dryv_amd/lib/var
 SRC="dryv_amd/csrc/recon_band.hip dryv_amd/csrc/output_pack.hip dryv_amd/csrc/deblock.hip dryv_amd/csrc/recon_api.hip"
-[ -f dryv_amd/csrc/recon_kernel.hip ] && SRC="dryv_amd/csrc/recon_kernel.hip $SRC"
 while [ $# -gt 0 ]; do
   n=$1; f=$2; shift 2
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $f -o dryv_amd/lib/var/$n.so $SRC 2>/tmp/var_$n.err || { echo "build $n failed"; tail -5 /tmp/var_$n.err; } ) &

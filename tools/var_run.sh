@@ -36,7 +36,7 @@ for d in sorted(glob.glob('gpurun_out/var/pmc_*/')):
     acc=collections.defaultdict(list)
     for f in glob.glob(d+'/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'band_kernel' in r['Kernel_Name'] or 'recon_kernel' in r['Kernel_Name']:
+            if 'band_kernel' in r['Kernel_Name']:
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
     mb=300*120*68
     res.setdefault(n,{'ms':[]}).update({k: sum(v)/len(v)/mb for k,v in acc.items()})
