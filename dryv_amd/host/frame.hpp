@@ -4,7 +4,7 @@
 // (/root/reference/src/video/frame/mod.rs:16-90):
 //     Frame::new(&slice)              -> dryv::Frame(frame_params, ctx)
 //     frame.decode(&mut slice)        -> frame.decode(mb)                 once per macroblock, in mbaddr order
-//     frame.write_to_yuv_file(path)   -> frame.write_to_yuv_file(path)    same byte order (mod.rs:48-70)
+//     frame.write_to_yuv_file(path)   -> frame.write_to_yuv_file(path)    same byte order (frame/mod.rs:48-70)
 // `decode` is called from inside the CABAC macroblock loop (cabac/mod.rs:208); nothing the parser does
 // later depends on reconstructed samples, so here it only narrows the macroblock's fields into the
 // 16-byte record + 384 int16 coefficients of include/dryv_recon.h and appends them to the frame's batch.

@@ -72,12 +72,12 @@ static int decode_file(const char* in, const char* outp) {
   dryv_recon_ctx* ctx = nullptr;
   int st = dryv_recon_create(&ctx, 0);
   if (st != DRYV_OK) { std::fprintf(stderr, "dryv_recon_create: %s\n", dryv_recon_strerror(st)); return 3; }
-  dryv::Frame frame(P.fp, ctx);                                       // Frame::new(&slice)      decoder.rs:124
+  dryv::Frame frame(P.fp, ctx);                                       // Frame::new(&slice)      video/decoder.rs:124
   for (size_t a = 0; a < per; a++) {                                  // cabac/mod.rs:208
     st = frame.decode(unpack(P.mbs[a], &P.coeffs[a * DRYV_COEFFS_PER_MB]));
     if (st != DRYV_OK) { std::fprintf(stderr, "decode: %s\n", dryv_recon_strerror(st)); return 4; }
   }
-  st = frame.write_to_yuv_file(outp);                                 // decoder.rs:142
+  st = frame.write_to_yuv_file(outp);                                 // video/decoder.rs:142
   if (st != DRYV_OK) { std::fprintf(stderr, "reconstruct: %s\n", dryv_recon_strerror(st)); return 5; }
   dryv_recon_destroy(ctx);
   return 0;
@@ -191,14 +191,14 @@ int main(int argc, char** argv) {
   FILE* out = std::fopen(argv[2], "wb");
   if (!out) return 2;
   for (uint32_t fi = 0; fi < n_frames; fi++) {
-    dryv::Frame frame(fp, ctx);                                     // Frame::new(&slice)      decoder.rs:124
+    dryv::Frame frame(fp, ctx);                                     // Frame::new(&slice)      video/decoder.rs:124
     for (size_t a = 0; a < per; a++) {                              // slice.data(): the CABAC MB loop
       st = frame.decode(unpack(mbs[fi * per + a], &co[(fi * per + a) * DRYV_COEFFS_PER_MB]));  // cabac/mod.rs:208
       if (st != DRYV_OK) { std::fprintf(stderr, "decode: %s\n", dryv_recon_strerror(st)); return 4; }
     }
     const uint8_t* p;
     size_t bytes;
-    st = frame.planes(&p, &bytes);                                  // write_to_yuv_file       decoder.rs:142
+    st = frame.planes(&p, &bytes);                                  // write_to_yuv_file       video/decoder.rs:142
     if (st != DRYV_OK) { std::fprintf(stderr, "reconstruct: %s\n", dryv_recon_strerror(st)); return 5; }
     std::fwrite(p, 1, bytes, out);
   }

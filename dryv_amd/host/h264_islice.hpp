@@ -1172,7 +1172,7 @@ inline bool is_whole_picture_islice(const uint8_t* nal, size_t n) {
 }
 
 // Every picture of the stream that is a single I slice, up to max_pictures (the reference stops after sample 0:
-// decoder.rs:88, quirk Q9 -- a batch of pictures is this build's own unit of work), all under the stream's first SPS /
+// video/decoder.rs:88, quirk Q9 -- a batch of pictures is this build's own unit of work), all under the stream's first SPS /
 // PPS. Inter pictures in between are skipped; their count is returned in *skipped.
 // n_threads: intra pictures are independent of each other (CABAC contexts and the QP predictor restart with every slice:
 // cabac/mod.rs:72-87, slice/mod.rs:153), so their macroblock layers are parsed in parallel; 0 = one thread per hardware

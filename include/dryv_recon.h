@@ -137,7 +137,7 @@ int dryv_recon_sync(dryv_recon_ctx *ctx); /* waits, then reports the batch's sta
 
 /* The same, queued: may be called again before dryv_recon_sync, any number of times, each call with buffers of its own;
  * the batches run back to back on the context's stream with no host round trip between them (a decoder that fills
- * batch k+1 while batch k reconstructs: the reference's per-picture loop, decoder.rs:124-143, made asynchronous).
+ * batch k+1 while batch k reconstructs: the reference's per-picture loop, video/decoder.rs:124-143, made asynchronous).
  * dryv_recon_sync then waits for all of them and reports the OR of their status words; every queued batch's inputs
  * must stay valid until it returns. Only behind queued batches: DRYV_E_STATE if anything else is in flight, or if this
  * batch would need a larger workspace than the queue is running on (sync first). */

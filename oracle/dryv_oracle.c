@@ -56,7 +56,7 @@ enum { MODE_INTRA4X4 = 0, MODE_INTRA8X8 = 1, MODE_INTRA16X16 = 2, MODE_NA = 3 };
 
 /* What survives of a decoded macroblock for its neighbours: type + derived prediction modes. */
 typedef struct {
-  int unavailable; /* MbType::Unavailable (consts.rs:3 MB_UNAVAILABLE_INTRA)                   */
+  int unavailable; /* MbType::Unavailable (slice/consts.rs:3 MB_UNAVAILABLE_INTRA)                   */
   int mode;        /* PartPredMode of mb_type.mode() (macroblock.rs:593-599)                   */
   isize intra4x4_pred_mode[16];
   isize intra8x8_pred_mode[4];
@@ -1399,7 +1399,7 @@ int dryv_oracle_reconstruct(const dryv_frame_params *fp, uint32_t n_frames, cons
 
   int worst = DRYV_OK;
   for (uint32_t fi = 0; fi < n_frames; fi++) {
-    /* Frame::new + Slice::new: fresh planes and records per slice NAL (decoder.rs:123-124) */
+    /* Frame::new + Slice::new: fresh planes and records per slice NAL (video/decoder.rs:123-124) */
     memset(fr.luma_data, 0, nl);
     memset(fr.chroma_cb_data, 0, nc);
     memset(fr.chroma_cr_data, 0, nc);
