@@ -218,7 +218,8 @@ struct Args {
   const dryv_mb_desc* mbs;
   const int16_t* coeffs;
   uint8_t* yuv;
-  unsigned* status;
+  unsigned* status;     // [0] bit 0 unsupported record, bit 1 a block beyond the fast build's arithmetic, bit 2 a band gave up waiting;
+                        // [1..3] where it gave up; [4] ~(sequence number of the first queued batch that raised bit 1)
   unsigned* progY;      // [frame][band]: macroblocks of the band's last row whose bottom luma line is visible
   unsigned* progC;      // [frame][band]: the same for its bottom chroma lines
   unsigned* progM;      // [frame][band]: W once the band's mode records (below) are visible
@@ -226,6 +227,7 @@ struct Args {
   unsigned* taskCounter;
   unsigned long long* profile;  // DRYV_BAND_PROFILE builds only
   int waveBase;                 // (global index of the workgroup's first wave, for the same)
+  unsigned batchSeq;            // position of this launch in the host's queue of batches (status[4])
 };
 
 
@@ -497,7 +499,7 @@ WV int max_abs16(const u32x4 c0, const u32x4 c1, bool skip0) {
 // fast build then knows no more than that; the WIDE build carries the exact value in dcWide).
 template <bool WIDE, typename F>
 WV void residual_pass(const u32x4 c0, const u32x4 c1, int ldsBase, int qp, bool useDc, int dc, bool dcHuge, long long dcWide,
-                      bool unused, unsigned* status, unsigned out[8], F&& inputsDone) {
+                      bool unused, unsigned* status, unsigned batchSeq, unsigned out[8], F&& inputsDone) {
   const u32x4 q = wv::lds_u128(ldsBase + T_QP + 32 * qp);   // everything the pass derives from qp (build_tables)
   if (!wv::any(!unused && !block_fits16(c0, c1, q.z & 0xffffu, useDc, dc, dcHuge))) {
     const u32x4 lq0 = wv::lds_u128(ldsBase + T_LS4Q + 32 * qp), lq1 = wv::lds_u128(ldsBase + T_LS4Q + 32 * qp + 16);
@@ -518,6 +520,7 @@ WV void residual_pass(const u32x4 c0, const u32x4 c1, int ldsBase, int qp, bool 
     }
   } else if (big) {
     wv::atomic_or(status, 2u);
+    wv::atomic_max(status + 4, ~batchSeq);   // (the earliest flagged batch of a queue: the host re-runs from there)
   }
   const u32x4 l0 = wv::lds_u128(lsAddr), l1 = wv::lds_u128(lsAddr + 16);
   idct4x4<int>(c0, c1, l0, l1, shl, rnd, shr, useDc, dc, out);
@@ -605,7 +608,7 @@ WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts,
 // is a valid Intra8x8 one. Overflow handling as in residual_pass (thr8: |d| <= 2^23 keeps both 8-point passes in int32).
 template <bool WIDE>
 WV void residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp, int ldsBase, int ts, unsigned* status,
-                    unsigned out[8]) {
+                    unsigned batchSeq, unsigned out[8]) {
   const int g = lane >> 4, i = lane & 15;
   const int thr = (int)wv::lds_u16(ldsBase + T_THR8 + 2 * qp);
   bool big = false;
@@ -627,6 +630,7 @@ WV void residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp,
     }
   } else if (big) {
     wv::atomic_or(status, 2u);
+    wv::atomic_max(status + 4, ~batchSeq);
   }
   residual8x8_passes<int>(mine, g, i, qp, ldsBase, ts, out);
 }
@@ -1087,12 +1091,12 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         // (the next step's coefficients are requested from inside the pass, as soon as this step's have been read. The Intra8x8
         // pass below reads them again: such a stream requests them behind it)
         const u32x4 cC0 = cA0, cC1 = cA1;
-        residual_pass<WIDE>(cC0, cC1, ldsBase, qp, kind == 2, dcY, kind == 2 && dcHuge, dcWide, HAS_I8 && kind == 1, A.status, rA,
+        residual_pass<WIDE>(cC0, cC1, ldsBase, qp, kind == 2, dcY, kind == 2 && dcHuge, dcWide, HAS_I8 && kind == 1, A.status, A.batchSeq, rA,
                             [&]() { if (!HAS_I8 && !EXP_DUP_IS(0)) load_coefs_luma(s + 1, kN1); });
         // Intra8x8 macroblocks: their lanes' rA becomes 16 residuals of one column per 8x8 block pass (residual8x8)
         if (HAS_I8 && wv::any(valid && kind == 1)) {
           unsigned r8[8];
-          residual8x8<WIDE>(cC0, cC1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, r8);
+          residual8x8<WIDE>(cC0, cC1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, A.batchSeq, r8);
 #pragma unroll
           for (int k = 0; k < 8; k++) rA[k] = kind == 1 ? r8[k] : rA[k];
         }
@@ -1388,7 +1392,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
           dcHuge = (unsigned)(v + (int)lim - 1) > 2u * lim - 2u;
           dcC = (int)((unsigned)(v * (int)qq.x) << qq.y) >> 5;
         }
-        EXP_REP(6) residual_pass<WIDE>(cB0, cB1, ldsBase, qc, true, dcC, dcHuge, dcWide, false, A.status, rB, []() {});
+        EXP_REP(6) residual_pass<WIDE>(cB0, cB1, ldsBase, qc, true, dcC, dcHuge, dcWide, false, A.status, A.batchSeq, rB, []() {});
         if (wv::any(kindR == 3)) {
 #pragma unroll
           for (int k = 0; k < 8; k++) rB[k] = kindR == 3 ? 0u : rB[k];

@@ -17,6 +17,6 @@ size_t band_workspace_bytes(const KParams& P);
 size_t band_reset_bytes(const KParams& P);      // leading bytes of the workspace a launch needs zeroed
 size_t band_profile_offset(const KParams& P);   // diagnostic builds: per-wave phase sums / breadcrumbs behind the workspace
 hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                       void* d_workspace, int grid, bool wide, hipStream_t stream);
+                       void* d_workspace, int grid, bool wide, unsigned batch_seq, hipStream_t stream);
 
 }  // namespace dryv

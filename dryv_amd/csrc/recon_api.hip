@@ -61,6 +61,7 @@ struct dryv_recon_ctx {
   void* last_yuv = nullptr;
   bool last_band = false;
   int wide_reruns = 0;
+  int wide_rerun_batches = 0;   // batches that were launched again with the wide build
   // device-resident batches queued since the last sync (dryv_recon_submit_device_queued): kept for the wide re-run
   struct Queued { KParams P; const void* mbs; const void* coeffs; void* yuv; };
   std::vector<Queued> queued;
@@ -127,11 +128,11 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   next_events(ctx);
   e = hipEventRecord(ctx->ev_start, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, ctx->stream);
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, (unsigned)ctx->queued.size(), ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "band_kernel launch");
   e = hipEventRecord(ctx->ev_stop, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream);
+  e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemcpyAsync(status)");
   ctx->timed = true;
   return DRYV_OK;
@@ -148,7 +149,7 @@ int launch_chunk(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, false);
   grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
   if ((e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
-  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, ctx->stream);
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, 0u, ctx->stream);
   return e == hipSuccess ? DRYV_OK : fail(ctx, e, "band_kernel launch");
 }
 
@@ -164,9 +165,10 @@ int finish(dryv_recon_ctx* ctx) {
       // a block beyond int32: the whole batch again, unpipelined, with the band kernel's wide
       // build (never for a conformant stream)
       ctx->wide_reruns++;
+      ctx->wide_rerun_batches++;
       ctx->last_band = true;
       const KParams& P = ctx->last_P;
-      if ((e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
+      if ((e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
       int st = launch_band(ctx, P, ctx->d_mbs, ctx->d_coeffs, ctx->d_yuv, true);
       if (st != DRYV_OK) return st;
       e = hipMemcpyAsync(ctx->piped_out, ctx->d_yuv, (size_t)P.n_frames * P.W * P.H * 384, hipMemcpyDeviceToHost, ctx->stream);
@@ -177,15 +179,20 @@ int finish(dryv_recon_ctx* ctx) {
   if (*ctx->h_status & 2u) {
     ctx->wide_reruns++;
     ctx->last_band = true;
-    e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
+    e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream);
     if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
     int st = DRYV_OK;
     if (ctx->queued.size() > 1) {
-      // several batches were queued behind each other and the status word does not say which of them raised the flag:
-      // all of them again with the wide build, in order
-      for (const dryv_recon_ctx::Queued& q : ctx->queued)
+      // several batches were queued behind each other: status word 4 names the first one that raised the flag (a launch
+      // carries its position in the queue); that one and everything behind it again with the wide build, in order
+      const unsigned first = std::min<unsigned>(~ctx->h_status[4], (unsigned)ctx->queued.size() - 1u);
+      std::vector<dryv_recon_ctx::Queued> again(ctx->queued.begin() + first, ctx->queued.end());
+      ctx->queued.clear();   // (the re-runs are launches of their own: sequence numbers from 0)
+      ctx->wide_rerun_batches += (int)again.size();
+      for (const dryv_recon_ctx::Queued& q : again)
         if ((st = launch_band(ctx, q.P, q.mbs, q.coeffs, q.yuv, true)) != DRYV_OK) break;
     } else {
+      ctx->wide_rerun_batches++;
       st = launch_band(ctx, ctx->last_P, ctx->last_mbs, ctx->last_coeffs, ctx->last_yuv, true);
     }
     if (st != DRYV_OK) return st;
@@ -206,7 +213,7 @@ int launch(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const void*
   int st = ensure(ctx, &ctx->d_work, &ctx->cap_work, workspace_bytes(P));
   if (st != DRYV_OK) return st;
   hipError_t e = hipSuccess;
-  if (reset_status) e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
+  if (reset_status) e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
   // Persistent grid: every team keeps claiming 4-row bands until none are left, so a smaller grid is merely slower and
   // never incorrect.
@@ -246,8 +253,8 @@ int dryv_recon_create(dryv_recon_ctx** out, int device_ordinal) {
   ctx->device = device_ordinal;
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipMalloc((void**)&ctx->d_status, 16)) != hipSuccess ||
-      (e = hipHostMalloc((void**)&ctx->h_status, 16, hipHostMallocDefault)) != hipSuccess) {
+      (e = hipMalloc((void**)&ctx->d_status, 32)) != hipSuccess ||
+      (e = hipHostMalloc((void**)&ctx->h_status, 32, hipHostMallocDefault)) != hipSuccess) {
     dryv_recon_destroy(ctx);
     return DRYV_E_DEVICE;
   }
@@ -376,7 +383,7 @@ int dryv_recon_deblock_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, 
   (void)hipSetDevice(ctx->device);
   if ((st = ensure(ctx, &ctx->d_dbwork, &ctx->cap_dbwork, dryv::deblock::workspace_bytes(P))) != DRYV_OK) return st;
   hipError_t e = hipMemsetAsync(ctx->d_dbwork, 0, dryv::deblock::reset_bytes(P), ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(deblock workspace)");
   const long long tasks = 2ll * P.n_frames * ((P.H + 3) / 4);  // a luma and a chroma task per band
   const int wpb = dryv::deblock_waves_per_block();
@@ -386,7 +393,7 @@ int dryv_recon_deblock_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, 
   if ((e = dryv::deblock_launch(P, d_mbs, d_yuv, ctx->d_status, ctx->d_dbwork, (int)grid, ctx->stream)) != hipSuccess)
     return fail(ctx, e, "deblock_kernel launch");
   if ((e = hipEventRecord(ctx->ev_stop, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  if ((e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+  if ((e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
     return fail(ctx, e, "hipMemcpyAsync(status)");
   ctx->timed = true;
   ctx->deblock_pending = true;
@@ -472,7 +479,7 @@ int dryv_recon_submit_host(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uin
     ctx->ev_in.push_back(a);
     ctx->ev_k.push_back(b);
   }
-  if ((e = hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
+  if ((e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
   st = ensure(ctx, &ctx->d_work, &ctx->cap_work, workspace_bytes(P));
   if (st != DRYV_OK) return st;
   if ((e = hipEventRecord(ctx->ev_start, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
@@ -494,7 +501,7 @@ int dryv_recon_submit_host(dryv_recon_ctx* ctx, const dryv_frame_params* fp, uin
       return fail(ctx, e, "chunk copy-out");
   }
   if ((e = hipEventRecord(ctx->ev_stop, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  if ((e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+  if ((e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
     return fail(ctx, e, "hipMemcpyAsync(status)");
   ctx->timed = true;
   ctx->last_P = P;
@@ -541,6 +548,13 @@ int dryv_recon_submit_device_queued(dryv_recon_ctx* ctx, const dryv_frame_params
   ctx->queued.push_back(dryv_recon_ctx::Queued{P, d_mbs, d_coeffs, d_yuv_out});
   ctx->in_flight = true;
   ctx->in_flight_host = false;
+  return DRYV_OK;
+}
+
+int dryv_recon_wide_rerun_stats(dryv_recon_ctx* ctx, int* events, int* batches) {
+  if (!ctx) return DRYV_E_INVALID;
+  if (events) *events = ctx->wide_reruns;
+  if (batches) *batches = ctx->wide_rerun_batches;
   return DRYV_OK;
 }
 

@@ -84,7 +84,7 @@ size_t band_workspace_bytes(const KParams& P) { return band_profile_offset(P); }
 
 // wide: the build whose residual passes fall back to 64-bit arithmetic (see band_kernel.h, residual_pass).
 hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                       void* d_workspace, int grid, bool wide, hipStream_t stream) {
+                       void* d_workspace, int grid, bool wide, unsigned batch_seq, hipStream_t stream) {
   unsigned char* wsb = (unsigned char*)d_workspace;
   band::Args A;
   A.mbs = (const dryv_mb_desc*)d_mbs;
@@ -98,6 +98,7 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   A.rowModes = (unsigned*)(wsb + 256 + band_prog_bytes(P));
   A.profile = nullptr;
   A.waveBase = 0;
+  A.batchSeq = batch_seq;
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE) || defined(DRYV_BAND_TIMELINE)
   A.profile = (unsigned long long*)(wsb + band_profile_offset(P));
 #endif

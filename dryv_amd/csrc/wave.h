@@ -123,6 +123,7 @@ WV unsigned ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_REL
 WV void st_sc1(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV unsigned atomic_add_task(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 WV void atomic_or(unsigned* p, unsigned v) { atomicOr(p, v); }
+WV void atomic_max(unsigned* p, unsigned v) { atomicMax(p, v); }
 struct __attribute__((packed, aligned(2))) U128a2 { u32x4 v; };
 WV u32x4 ld_u128_a2(const void* p) { return ((const U128a2*)p)->v; }  // 2-byte-aligned 16-byte load (global_load_dwordx4)
 struct __attribute__((packed, aligned(4))) U128a4 { u32x4 v; };

@@ -177,6 +177,12 @@ class ReconContext:
         _check(self._lib.dryv_recon_kernel_ms_stats(self._h, int(n_last), C.byref(a), C.byref(lo), C.byref(hi)), self._h)
         return float(a.value), float(lo.value), float(hi.value)
 
+    def wide_rerun_stats(self):
+        """(events, batches): syncs that found a batch flagged for the 64-bit build, and batches launched again because of it."""
+        a, b = C.c_int(), C.c_int()
+        _check(self._lib.dryv_recon_wide_rerun_stats(self._h, C.byref(a), C.byref(b)), self._h)
+        return int(a.value), int(b.value)
+
     def sync(self, allow_unsupported=False):
         st = self._lib.dryv_recon_sync(self._h)
         if not (allow_unsupported and st == abi.DRYV_E_UNSUPPORTED):

@@ -55,6 +55,8 @@ def _load():
             getattr(_lib, "dryv_h264_batch_" + n).restype = rt
             getattr(_lib, "dryv_h264_batch_" + n).argtypes = [C.c_void_p]
         _lib.dryv_h264_batch_crop.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.dryv_h264_bin_log.restype = C.c_longlong
+        _lib.dryv_h264_bin_log.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.dryv_h264_encode_stream.restype = C.c_longlong
         _lib.dryv_h264_encode_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_size_t]
@@ -198,3 +200,19 @@ def stream_params(data):
 def _capacity_pictures(data, capacity_mbs):
     fp, _ = stream_params(data)
     return capacity_mbs // (fp.pic_width_in_mbs * fp.pic_height_in_mbs)
+
+
+def bin_log(data, picture=0):
+    """Test hook: (bins, W, H, transform_8x8_mode_flag, slice_qp) of the stream's `picture`-th intra picture: every CABAC bin the
+    parser decoded, in order, as value | kind << 1 (kind 0 context-coded, 1 bypass, 2 terminate). Input of the independent
+    restatement of the slice-data syntax in oracle/islice_syntax.py."""
+    lib = _load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    hdr = np.zeros(4, dtype=np.int32)
+    need = lib.dryv_h264_bin_log(buf.ctypes.data, buf.size, int(picture), None, 0, hdr.ctypes.data)
+    if need == 0:
+        raise H264Error(lib.dryv_h264_last_error().decode())
+    out = np.zeros(-need, dtype=np.uint8)
+    got = lib.dryv_h264_bin_log(buf.ctypes.data, buf.size, int(picture), out.ctypes.data, out.size, hdr.ctypes.data)
+    assert got == out.size
+    return out, int(hdr[0]), int(hdr[1]), int(hdr[2]), int(hdr[3])

@@ -169,6 +169,26 @@ long long dryv_h264_parse_all_into(const uint8_t* data, size_t n, size_t max_pic
   }
   DRYV_CATCH_ALL(0)
 }
+/* Test hook: the CABAC bins (value | kind << 1; kind 0 context-coded, 1 bypass, 2 terminate) of the stream's `picture`-th
+ * intra picture, in decoding order, for an independent restatement of the slice-data syntax to parse. hdr4 = picture width
+ * and height in macroblocks, transform_8x8_mode_flag, SliceQPY. Returns the number of bins (negated if `cap` is smaller; call
+ * with cap = 0 to size the buffer), 0 on failure. */
+long long dryv_h264_bin_log(const uint8_t* data, size_t n, size_t picture, uint8_t* out, size_t cap, int* hdr4) {
+  try {
+    std::vector<uint8_t> bins;
+    const ParsedFrame F = parse_islice_with_bins(data, n, picture, bins);
+    if (hdr4) {
+      hdr4[0] = F.fp.pic_width_in_mbs;
+      hdr4[1] = F.fp.pic_height_in_mbs;
+      hdr4[2] = F.fp.transform_8x8_mode_flag;
+      hdr4[3] = F.slice_qp;
+    }
+    if (bins.size() > cap) return -(long long)bins.size();
+    memcpy(out, bins.data(), bins.size());
+    return (long long)bins.size();
+  }
+  DRYV_CATCH_ALL(0)
+}
 void dryv_h264_batch_free(dryv_h264_batch* b) { delete b; }
 size_t dryv_h264_batch_pictures(const dryv_h264_batch* b) { return b->F.size(); }
 size_t dryv_h264_batch_skipped(const dryv_h264_batch* b) { return b->skipped; }   /* coded slices that were not whole intra pictures */

@@ -382,6 +382,13 @@ struct CabacDecoder {
   CabacContexts c;
   unsigned range = 510, offset = 0;
   long bins = 0;
+  // test hook: every decoded bin in order, value | kind << 1 (kind 0 context-coded, 1 bypass, 2 terminate): what an
+  // independent restatement of the syntax (oracle/islice_syntax.py) parses to check this parser's record / list mapping
+  std::vector<uint8_t>* log = nullptr;
+  unsigned note(unsigned bin, unsigned kind) {
+    if (log) log->push_back((uint8_t)(bin | (kind << 1)));
+    return bin;
+  }
   void start(BitReader* br, int slice_qp) {
     r = br;
     c.init(slice_qp);
@@ -407,26 +414,26 @@ struct CabacDecoder {
       range <<= 1;
       offset = (offset << 1) | r->bit();
     }
-    return bin;
+    return note(bin, 0);
   }
   unsigned bypass() {
     bins++;
     offset = (offset << 1) | r->bit();
     if (offset >= range) {
       offset -= range;
-      return 1;
+      return note(1, 1);
     }
-    return 0;
+    return note(0, 1);
   }
   unsigned terminate() {
     bins++;
     range -= 2;
-    if (offset >= range) return 1;
+    if (offset >= range) return note(1, 2);
     while (range < 256) {
       range <<= 1;
       offset = (offset << 1) | r->bit();
     }
-    return 0;
+    return note(0, 2);
   }
 };
 
@@ -924,7 +931,7 @@ inline void set_params(dryv_frame_params& fp, const Sps& s, const Pps& p) {
 // mbs_out / co_out: where the picture's records and coefficients go (W * H records, W * H * 384 coefficients, e.g. a
 // slice of a page-locked batch buffer); NULL = into the returned ParsedFrame's own vectors.
 inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, const Pps& p, dryv_mb_desc* mbs_out = nullptr,
-                                    int16_t* co_out = nullptr) {
+                                    int16_t* co_out = nullptr, std::vector<uint8_t>* bin_log = nullptr) {
   if (n < 2) fail("empty NAL unit");
   const int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
   if (type != 5 && type != 1) fail("not a slice NAL unit");
@@ -953,6 +960,7 @@ inline ParsedFrame parse_islice_nal(const uint8_t* nal, size_t n, const Sps& s, 
   F.deblock.slice_alpha_c0_offset_div2 = (int8_t)h.alpha_c0_offset_div2;
   F.deblock.slice_beta_offset_div2 = (int8_t)h.beta_offset_div2;
   CabacDecoder cd;
+  cd.log = bin_log;
   cd.start(&r, h.slice_qp);
   MbLayer<false, CabacDecoder> L(cd, W, H, p.transform8x8, h.slice_qp);
   for (int a = 0; a < W * H; a++) {
@@ -1238,6 +1246,18 @@ inline std::vector<ParsedFrame> parse_all_islices(const uint8_t* f, size_t n, si
   for (const std::string& e : errs)
     if (!e.empty()) fail(e.c_str());
   return out;
+}
+
+// Test hook: the CABAC bins of the stream's `picture`-th intra picture (see CabacDecoder::log) and its parse.
+inline ParsedFrame parse_islice_with_bins(const uint8_t* f, size_t n, size_t picture, std::vector<uint8_t>& bins) {
+  const bool mp4 = n >= 12 && memcmp(f + 4, "ftyp", 4) == 0;
+  Stream S = mp4 ? demux_mp4(f, n, (size_t)-1) : demux_annexb(f, n);
+  size_t k = 0;
+  for (const Stream::Nal& nal : S.slices) {
+    if (!is_whole_picture_islice(nal.p, nal.n)) continue;
+    if (k++ == picture) return parse_islice_nal(nal.p, nal.n, S.sps_of(nal), S.pps_of(nal), nullptr, nullptr, &bins);
+  }
+  fail("no such intra picture");
 }
 
 // ---- encoder: one IDR picture as an Annex-B byte stream (SPS, PPS, one I slice) ------------------------------------------

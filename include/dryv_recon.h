@@ -193,6 +193,11 @@ int dryv_recon_last_kernel_ms(dryv_recon_ctx *ctx, float *ms);
  * remembered; every launch is bracketed by an event pair of its own, so queued launches are timed one by one). Any of the
  * three pointers may be NULL. Valid after wait/sync. */
 int dryv_recon_kernel_ms_stats(dryv_recon_ctx *ctx, uint32_t n_last, float *avg_ms, float *min_ms, float *max_ms);
+/* Diagnostics of the 64-bit fallback: how many times a sync / wait found a batch flagged by the fast kernel build (a
+ * block beyond its 32-bit arithmetic: no conformant stream has one), and how many batches were launched again with the
+ * wide build because of it. A queue of batches is re-run from the first flagged batch on, not from its head. Either
+ * pointer may be NULL. */
+int dryv_recon_wide_rerun_stats(dryv_recon_ctx *ctx, int *events, int *batches);
 
 /* Raw HIP stream handle (hipStream_t) the context launches on, for callers that want to order
  * their own work or record their own events against it. */

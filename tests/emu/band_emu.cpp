@@ -132,13 +132,13 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
   const int nBands = (g_P.H + 3) / 4;
   std::vector<unsigned> prog((size_t)3 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H * dryv::band::MREC_WORDS, 0xEEEEEEEEu);
   // like the host API: the fast build first; if it flags a block beyond int32 (status bit 1), the batch again with the wide build
-  unsigned status[4] = {0, 0, 0, 0};
+  unsigned status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int pass = 0; pass < 2; pass++) {
     unsigned counter = 0;
     memset(status, 0, sizeof status);
     std::fill(prog.begin(), prog.end(), 0u);
     g_wide = pass == 1;
-    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, prog.data() + (size_t)2 * n_frames * nBands, modes.data(), &counter, nullptr, 0};
+    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, prog.data() + (size_t)2 * n_frames * nBands, modes.data(), &counter, nullptr, 0, 0u};
     wv::g_body = body;
     std::vector<std::unique_ptr<wv::Wave>> waves;
     const int teamBytes = dryv::band::team_bytes(g_P.transform8x8 != 0, true);   // (one size for both passes: the wide build's)

@@ -174,6 +174,7 @@ WV unsigned ld_sc1(const unsigned* p) { return *(const volatile unsigned*)p; }
 WV void st_sc1(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
 WV unsigned atomic_add_task(unsigned* p, unsigned v) { const unsigned o = *p; *p += v; return o; }
 WV void atomic_or(unsigned* p, unsigned v) { *p |= v; }
+WV void atomic_max(unsigned* p, unsigned v) { if (v > *p) *p = v; }
 WV u32x4 ld_u128_a2(const void* p) { u32x4 v; memcpy(&v, p, 16); return v; }
 WV void st_g128(void* p, u32x4 v) { memcpy(p, &v, 16); }
 WV void st_g64(void* p, u32x2 v) { memcpy(p, &v, 8); }

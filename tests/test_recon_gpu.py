@@ -236,7 +236,8 @@ def test_queued_device_submits(recon_ctx):
         if big:
             co = np.where(np.arange(co.size).reshape(co.shape) % 2 == 0, 32767, -32768).astype(np.int16)
         cases.append((frames, mbs, co))
-    for use in ([0, 2, 0], [0, 1, 2]):   # without / with the batch that needs the wide re-run
+    for use in ([0, 2, 0], [0, 1, 2], [0, 2, 0, 1]):   # without / with the batch that needs the wide re-run (in the middle, last)
+        ev0, nb0 = recon_ctx.wide_rerun_stats()
         bufs = []
         for k in use:
             frames, mbs, co = cases[k]
@@ -253,6 +254,9 @@ def test_queued_device_submits(recon_ctx):
         recon_ctx.sync()
         avg, lo, hi = recon_ctx.kernel_ms_stats(len(bufs))
         assert 0 < lo <= avg <= hi
+        # the queue is re-run from the first flagged batch on (status word 4 carries its position), not from its head
+        ev1, nb1 = recon_ctx.wide_rerun_stats()
+        assert (ev1 - ev0, nb1 - nb0) == ((1, len(use) - use.index(1)) if 1 in use else (0, 0))
         for k, d_m, d_c, d_o in bufs:
             frames, mbs, co = cases[k]
             st, want = oracle.reconstruct(fp, frames, mbs, co)
