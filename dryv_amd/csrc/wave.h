@@ -161,6 +161,8 @@ template <int P>
 WV void setprio() { __builtin_amdgcn_s_setprio(P); }
 // the value, behind a barrier the optimiser cannot see through: what is derived from it is recomputed, not kept live
 WV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// a use of v the optimiser cannot remove (the loaded value of a cache-warming load: the load stays, its wait lands here)
+WV void consume(unsigned v) { asm volatile("" : : "v"(v)); }
 
 }  // namespace wv
 

@@ -188,6 +188,7 @@ WV void compiler_fence() {}
 template <int P>
 WV void setprio() {}
 WV int opaque(int v) { return v; }
+WV void consume(unsigned) {}
 
 }  // namespace wv
 #ifndef __HIPCC__
