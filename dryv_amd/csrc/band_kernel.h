@@ -1,4 +1,5 @@
 // band_kernel.h — macroblock reconstruction, one TEAM of three wavefronts per band of four macroblock rows (gfx950).
+// The one reconstruction kernel of the library: every stream (with or without the 8x8 transform; fast and WIDE builds).
 //
 // Decomposition
 //   * The unit of work is a band: 4 consecutive macroblock rows of one frame. Lanes 16g..16g+15 of a wave belong to
@@ -6,24 +7,26 @@
 //     x = s - 2g, so neighbours A, B, C, D of every macroblock (slice/mod.rs:576-613) were finished by the same wave
 //     one or two steps earlier -- no synchronisation between the rows of a band at all.
 //   * A band is worked on by a team of three waves of one workgroup that run on different SIMDs:
-//       FRONT   record decode, luma residuals (into a double-buffered LDS area), Intra4x4/8x8 mode derivation, and
-//               the fetch of the band above's bottom luma lines for BACK;
-//       BACK    luma prediction (Intra16x16, the Intra4x4 block wavefront), luma staging, stores: the only wave on
-//               the frame's critical path, and it never touches global memory except to store;
+//       FRONT   the step's record for BACK: luma residuals (into a queue of records in LDS), the step's slice of the
+//               band's mode records, and the fetch of the band above's bottom luma lines;
+//       BACK    luma prediction (Intra16x16, the Intra4x4 block wavefront, Intra8x8), luma staging, stores: the only wave
+//               on the frame's critical path, and it never touches global memory except to store;
 //       CHROMA  all of chroma (residuals, prediction, staging, stores, hand-off): nothing in it depends on a luma
-//               pixel or on the other two waves; it only takes the team's task numbers from FRONT.
+//               pixel or on the other two waves -- and, between two tasks, the next band's prediction modes (band_modes:
+//               a pre-pass over the whole band, one lane per macroblock).
 //     FRONT -> BACK coupling is the per-step record in LDS (residuals, table rows, macroblock kinds) and two LDS words
 //     per buffer (ready / free). A lone wave issues about one instruction every 4-5 cycles whatever its kind, so a
 //     step's latency is the instruction count of the slowest wave; the split cuts it, and with it the frame's critical
 //     path (a frame is a 2:1 wavefront of 120 + 2 x 67 macroblock steps that no amount of parallel frames shortens).
 //   * Bands come off one queue in band-major order (band 0 of every frame, band 1 of every frame, ...): a band's
-//     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running or done, so
-//     there is no deadlock at any residency.
+//     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running, done, or some
+//     team's next task, so there is no deadlock at any residency. FRONT claims a team's next task DRYV_BAND_CLAIM_AHEAD
+//     steps before the current one ends, so that CHROMA -- ahead of the luma waves inside a task -- has it in time.
 //   * Between bands the hand-off goes through L2 (MI355X_MICROARCH.md "valid forms", sc1 stores + drained flag,
 //     sc1 loads), separately for luma (BACK stores, the FRONT of the band below fetches), chroma (CHROMA) and the
-//     bottom-row modes (FRONT): the band's last row stores them write-through and, a good part of a step later --
-//     when s_waitcnt vmcnt(0) has shown those stores complete -- publishes its progress word. The band below reads
-//     that word one step ahead and fetches one macroblock's lines per step.
+//     mode records (CHROMA's pre-pass; one flag per band): the band's last row stores its lines write-through and, a good
+//     part of a step later -- when s_waitcnt vmcnt(0) has shown those stores complete -- publishes its progress word.
+//     The band below reads that word one step ahead and fetches one macroblock's lines per step.
 //
 // Inside a step (4 macroblocks)
 //   * residual: ONE LANE PER 4x4 BLOCK. The lane loads its block's 16 coefficients (32 contiguous bytes of the
@@ -31,19 +34,20 @@
 //     passes are in-lane, and no transpose exists. Luma: 64 lanes = 4 MB x 16 blocks; chroma: 32 lanes = 4 MB x
 //     2 planes x 4 blocks, so CHROMA computes two steps' residuals per pass and then hands the halves over
 //     (v_permlane32_swap): every step's chroma prediction runs on all 64 lanes, half a block per lane.
-//     Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP.
-//     int32 arithmetic with a per-qp coefficient bound (KParams::thr4). A block beyond it flags the batch, and the
-//     host re-runs the batch with the WIDE build of this kernel, whose passes switch to int64 (reference: isize)
+//     Intra16x16 DC: 4x4 Hadamard over the 16 lanes of the row group by DPP. What a pass derives from qp comes from one
+//     LDS table row (T_QP). Packed 16-bit arithmetic where the block provably fits, int32 with a per-qp coefficient
+//     bound (KParams::thr4) otherwise. A block beyond that flags the batch, and the host re-runs it (from the first
+//     flagged batch of a queue) with the WIDE build of this kernel, whose passes switch to int64 (reference: isize)
 //     for such waves: the result is the reference's for every int16 input.
 //   * Intra16x16 and chroma prediction use the same lane-per-block layout: V, H and DC are one v_perm_b32
 //     byte-select per pixel pair, plane is packed 16-bit arithmetic.
-//   * Intra4x4: prediction modes by the 7-sweep DPP relaxation over the block grid (one DPP row per macroblock),
-//     pixels by a 10-step 2:1 block wavefront with 8 lanes per block (2 pixels each; 16 lanes and one pixel each
-//     in the four rounds that have one block per macroblock): every pixel is (E[p] + 2E[q] + E[r] + 2) >> 2 of
-//     three samples whose tile offsets come from a per-(mode, pixel) table.
+//   * Intra4x4 / Intra8x8 prediction modes: not here -- band_modes, once per band. Intra4x4 pixels by a 10-step 2:1 block
+//     wavefront with 8 lanes per block (2 pixels each; 16 lanes and one pixel each in the four rounds that have one
+//     block per macroblock): every pixel is (E[p] + 2E[q] + E[r] + 2) >> 2 of three samples whose tile offsets come
+//     from a per-(mode, pixel) table.
 //   * pixels are staged in LDS and stored as whole 64-byte row segments (NSY / NSC macroblocks at a time).
-//   * Whatever depends on the lane id alone is computed once per kernel where the registers allow (all of BACK; chosen
-//     constants in FRONT and CHROMA, which sit at the 80-register limit of six waves per SIMD).
+//   * Whatever depends on the lane id alone is computed once per kernel (BACK, FRONT's constants) or per task (CHROMA)
+//     where the registers allow: the fast build sits at the 80-register limit of six waves per SIMD.
 //
 // Written against wave.h: the same source runs on the GPU and, lane by lane, in the CPU emulator of tests/emu.
 #pragma once
@@ -93,14 +97,20 @@ constexpr int CW = 8 * NSC;      // chroma staging: bytes per pixel row
 constexpr int S_RES = 0;         // i16 [2][4][16 blk][16]  luma residual, [4 * by + bx][y][x]; a row group every RES_ROW bytes (512 + 32:
 constexpr int RES_ROW = 544;     //     8 banks behind the previous one: the rows of a band address their records alike in every
 constexpr int RES_BUF = 4 * RES_ROW;          //     instruction), a buffer every RES_BUF
-constexpr int S_MSEQ = S_RES + 2 * RES_BUF;   // u8  [2][4][2][12]  8 x the Intra4x4 table row per chain step and block half (always a multiple of 8)
-constexpr int S_INFO = S_MSEQ + 192;          // u32 [2][8]         kinds of the 4 macroblocks, Intra16x16 modes, task, step, parity, chain rounds with a DC block
-constexpr int S_FLAGS = S_INFO + 64;          // u32 ready[2], free[2] (global step count + 1 of the record in / consumed from the
+// the FRONT -> BACK record queue is NBUF steps deep (buffer = the team's global step count mod NBUF)
+#ifndef DRYV_BAND_NBUF
+#define DRYV_BAND_NBUF 2
+#endif
+constexpr int NBUF = DRYV_BAND_NBUF;
+static_assert(NBUF >= 2 && NBUF <= 4, "record queue depth");
+constexpr int S_MSEQ = S_RES + NBUF * RES_BUF;   // u8  [NBUF][4][2][12]  8 x the Intra4x4 table row per chain step and block half (always a multiple of 8)
+constexpr int S_INFO = S_MSEQ + 96 * NBUF;       // u32 [NBUF][8]      kinds of the 4 macroblocks, Intra16x16 modes, task, step, parity, chain rounds with a DC block
+constexpr int S_FLAGS = S_INFO + 32 * NBUF;      // u32 ready[4], free[4] (global step count + 1 of the record in / consumed from the
                                  //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks),
                                  //     modesDone (CHROMA -> FRONT: tasks whose mode pre-pass is through)
-constexpr int F_READY = 0, F_FREE = 8, F_TASKS = 16, F_HEAD = 32, F_TAILC = 36, F_MODES = 40;
+constexpr int F_READY = 0, F_FREE = 16, F_TASKS = 32, F_HEAD = 48, F_TAILC = 52, F_MODES = 56;
 // BACK (+ FRONT writes row 0 of the luma ring: lines fetched from the band above)
-constexpr int S_TILE = S_FLAGS + 64;  // u8  [4][NP][TILE_BYTES]  luma: tile (x >> 1) % NP, row j = y + 1, column 8 + 16 * (x & 1) + xr
+constexpr int S_TILE = (S_FLAGS + 64 + 63) & ~63;  // u8  [4][NP][TILE_BYTES]  luma: tile (x >> 1) % NP, row j = y + 1, column 8 + 16 * (x & 1) + xr
 constexpr int S_RINGY = S_TILE + 4 * NP * TILE_BYTES;  // bottom luma lines of the row above: row 0 [2][8][16], rows 1..3 [4][16]
 constexpr int S_LEFTY = S_RINGY + 448;            // u8 [4][16]     column 15 of the macroblock to the left
 // CHROMA
@@ -943,8 +953,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     bool claimedNext = false;
     if (task == TASK_END) {
       // tell BACK to stop: an end record in the next buffer
-      const int buf = (int)(gstep & 1u);
-      if (gstep >= 2) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - 1);
+      const int buf = (int)(gstep % (unsigned)NBUF);
+      if (gstep >= (unsigned)NBUF) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - NBUF + 1);
       if (lane0 == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 16, TASK_END);
       wv::wave_sync();
       if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);
@@ -954,13 +964,12 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     TLINE(task, 0, TNOW());
     TLINE(task, 3, A.waveBase + (int)(threadIdx.x >> 6));
     const BandGeo G = band_geo(task, nF, W, H);
-    const int r0 = G.r0, nR = G.nR, gl = G.gl, nSteps = G.nSteps;
-    const bool hasAbove = G.hasAbove, hasBelow = G.hasBelow;
+    const int r0 = G.r0, nR = G.nR, nSteps = G.nSteps;
+    const bool hasAbove = G.hasAbove;
     // per-frame bases (wave-uniform); everything below addresses them with 32-bit offsets: a frame's planes, records
     // and coefficients are each < 4 GB (the host API checks)
     const uint8_t* const planeY = A.yuv + (size_t)G.f * frameBytes;
     const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
-    const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
     const unsigned* const recF = A.rowModes + mbFrame * MREC_WORDS;   // the frame's mode records
     const unsigned* const upProgY = A.progY + (size_t)G.f * nBands + G.b - 1;
@@ -981,13 +990,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     // (the record's first word comes checked from the mode record: band_modes)
     auto load_kind = [&](int step) -> unsigned {
       const int l = lane0;
-#ifdef DRYV_EXP_KIND_FROM_DESC
-      return *(const unsigned*)(mbsF + 16u * mb_index(step, l >> 4));
-#elif defined(DRYV_EXP_KIND_PLAIN)
-      return *(recF + (MREC_WORDS * mb_index(step, l >> 4) + 5u));
-#else
       return wv::ld_sc1(recF + (MREC_WORDS * mb_index(step, l >> 4) + 5u));
-#endif
     };
     // word i (0..7) of the mode record of row g's macroblock, on lanes 16 g + i (i < 8)
     auto load_rec = [&](int step) -> unsigned {
@@ -1027,7 +1030,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         nextTask = claim_push(seq + 1);
         claimedNext = true;
       }
-      const int buf = (int)(gstep & 1u);
+      const int buf = (int)(gstep % (unsigned)NBUF);
       const unsigned kCur = kN1;  // first record word of this step's macroblock (checked: band_modes)
       const unsigned mCur = mN1;  // this lane's word of the step's mode record
       kN1 = kN2;                  // ... of step s+1
@@ -1141,7 +1144,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
 
       // ---- the step's record for BACK: residuals [blkIdx][y][x], table rows, kinds. The buffer is free once BACK has
       // finished the step two back.
-      if (gstep >= 2) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - 1);
+      if (gstep >= (unsigned)NBUF) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - NBUF + 1);
       if (HAS_I8 && kind == 1) {
         // this lane holds column j = i & 7 of 8x8 blocks i >> 3 (rA[0..3]) and 2 + (i >> 3) (rA[4..7]), rows 2m, 2m+1 per
         // word: element (row k, column j) goes to 4x4 block (bx, by) = (2 * (b8 & 1) + (j >> 2), 2 * (b8 >> 1) + (k >> 2)),
@@ -1265,13 +1268,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     // (the record's first word, checked, from the mode record: band_modes)
     auto load_kind = [&](int step) -> unsigned {
       const int l = lane0;
-#ifdef DRYV_EXP_KIND_FROM_DESC
-      return *(const unsigned*)(mbsF + 16u * mb_index(step + (l >> 5), (l >> 3) & 3));
-#elif defined(DRYV_EXP_KIND_PLAIN)
-      return *(recF + (MREC_WORDS * mb_index(step + (l >> 5), (l >> 3) & 3) + 5u));
-#else
       return wv::ld_sc1(recF + (MREC_WORDS * mb_index(step + (l >> 5), (l >> 3) & 3) + 5u));
-#endif
     };
     u32x4 cB0, cB1;
     int dcB;
@@ -1316,7 +1313,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       // 259 vector instructions per macroblock, but the shipped build keeps to zero spills)
       const int gc = (lane0 >> 3) & 3, cpl = (lane0 >> 2) & 1, cblk = lane & 3;
       const int ccx = cblk & 1, ccy = cblk >> 1, half = lane >> 5;
-      const int r = r0 + g, rC = r0 + gc;
+      const int rC = r0 + gc;
       const bool mbBC = rC > 0;
       const int x = s - 2 * g, xC = s - 2 * gc;
       const bool valid = g < nR && (unsigned)x < (unsigned)W, validC = gc < nR && (unsigned)xC < (unsigned)W;
@@ -1606,7 +1603,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
   int par = 0;  // task parity (row 0's luma ring)
 
   for (unsigned gstep = 0;; gstep++) {
-    const int buf = (int)(gstep & 1u);
+    const int buf = (int)(gstep % (unsigned)NBUF);
     team_wait(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);
     const unsigned task = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 16));
     if (task == TASK_END) break;

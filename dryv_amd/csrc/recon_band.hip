@@ -30,11 +30,12 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? D
   A.waveBase = (int)blockIdx.x * band::WAVES_PER_WG;
   band::build_tables(P, ldsBase, (int)threadIdx.x, (int)blockDim.x, HAS_I8);
   if (threadIdx.x < 64 * (blockDim.x / (64 * band::WAVES_PER_TEAM))) {
-    // the teams' flag words (16), and the table-row bytes of the block chain (48 words): some are never written (the
-    // second block half has no block in four of the ten rounds) and must still be offsets of table rows
+    // the teams' flag words (16), and the table-row bytes of the block chain (24 words per queued record): some are never
+    // written (the second block half has no block in four of the ten rounds) and must still be offsets of table rows
     const int q = (int)(threadIdx.x & 63);
     const int tsq = ldsBase + tEnd + (int)(threadIdx.x >> 6) * band::team_bytes(HAS_I8, WIDE);
-    wv::lds_st32(q < 16 ? tsq + band::S_FLAGS + 4 * q : tsq + band::S_MSEQ + 4 * (q - 16), 0u);
+    if (q < 16) wv::lds_st32(tsq + band::S_FLAGS + 4 * q, 0u);
+    for (int k = q; k < 24 * band::NBUF; k += 64) wv::lds_st32(tsq + band::S_MSEQ + 4 * k, 0u);
   }
   __syncthreads();  // the only workgroup-level synchronisation: the teams are independent from here on
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

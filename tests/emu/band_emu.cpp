@@ -154,7 +154,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
       if (w % WPT == 0) {
         dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
         memset(teamLds[w / WPT].data() + ldsBytes - teamBytes + dryv::band::S_FLAGS, 0, 64);  // the team's flags
-        memset(teamLds[w / WPT].data() + ldsBytes - teamBytes + dryv::band::S_MSEQ, 0, 192);  // (as the kernel's prologue does)
+        memset(teamLds[w / WPT].data() + ldsBytes - teamBytes + dryv::band::S_MSEQ, 0, 96 * dryv::band::NBUF);  // (as the kernel's prologue does)
       }
     }
     int live = n_waves;

@@ -28,7 +28,12 @@ def main():
     ctxs = []
     for p in a.libs:
         path = p if "/" in p else os.path.join(ROOT, "dryv_amd", "lib", "var", p if p.endswith(".so") else p + ".so")
-        lib = abi.load_library(path)
+        abi._preload_torch_hip_runtime()
+        lib = C.CDLL(path)   # (only the five entry points used here: older builds lack newer symbols)
+        lib.dryv_recon_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        lib.dryv_recon_submit_device_queued.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dryv_recon_sync.argtypes = [C.c_void_p]
+        lib.dryv_recon_kernel_ms_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         h = C.c_void_p()
         assert lib.dryv_recon_create(C.byref(h), 0) == 0
         ctxs.append((os.path.basename(path)[:-3], lib, h))
