@@ -369,10 +369,10 @@ def test_two_contexts_in_flight(recon_ctx):
 
 @pytest.mark.parametrize("qp_range", [(0, 24), (25, 40), (41, 51)])
 def test_full_int16_range_every_qp(recon_ctx, qp_range):
-    """The FFI carries int16 coefficients and scaling weights up to 255; the reference computes in 64-bit isize. Both
-    kernels compute in int32 and flag a macroblock beyond the bound under which that is provably the same (band kernel:
-    per block and qp; row kernel: one conservative bound per QPY); the library then re-runs the batch with the band
-    kernel's 64-bit build before reporting: bit-exact at every qp, with and without the 8x8 transform."""
+    """The FFI carries int16 coefficients and scaling weights up to 255; the reference computes in 64-bit isize. The fast
+    builds of the kernel compute in int32 (or packed 16 bits) and flag a macroblock beyond the bound under which that is
+    provably the same (per block and qp); the library then re-runs the batch with the kernel's 64-bit build before
+    reporting: bit-exact at every qp, with and without the 8x8 transform."""
     rng = np.random.default_rng(9 + qp_range[0])
     s4, s8 = rng.integers(1, 256, size=(6, 16)), rng.integers(1, 256, size=(6, 64))
     for lists, cfg in ((dict(), dict(i4x4=0.6, i8x8=0.0)), (dict(scaling4x4=s4), dict(i4x4=0.6, i8x8=0.0)),
@@ -471,7 +471,7 @@ def test_pipelined_host_path_chunk_boundaries(recon_ctx):
             recon_ctx.submit_host(fp, frames, mbs, co, out)
             recon_ctx.sync()
             assert np.array_equal(out, want), chunk
-        # a batch with blocks beyond int32 (wide re-run) and an 8x8 stream (row kernel) through the same path
+        # a batch with blocks beyond int32 (wide re-run) and an 8x8 stream through the same path
         os.environ["DRYV_RECON_CHUNK_FRAMES"] = "3"
         big = np.clip(co.astype(np.int64) * 6000, -32768, 32767).astype(np.int16)
         mb51 = mbs.copy()
@@ -552,8 +552,8 @@ def test_output_stage_crop_and_nv12(recon_ctx, geo):
 
 def test_exactness_bound_adversarial(recon_ctx):
     """Every coefficient exactly at (and one above) the per-qp bound of the band kernel's 32-bit path, with the sign patterns
-    that maximise the butterflies' growth; streams with the 8x8 transform go through the row kernel's conservative bound
-    and the re-run instead. All must equal the oracle's 64-bit arithmetic bit for bit."""
+    that maximise the butterflies' growth; streams with the 8x8 transform likewise (their 8x8 blocks against the bound of
+    the 8-point passes). All must equal the oracle's 64-bit arithmetic bit for bit."""
     V4 = np.array([[10, 16, 13], [11, 18, 14], [13, 20, 16], [14, 23, 18], [16, 25, 20], [18, 29, 23]])
     V8 = np.array([[20, 18, 32, 19, 25, 24], [22, 19, 35, 21, 28, 26], [26, 23, 42, 24, 33, 31], [28, 25, 45, 26, 35, 33],
                    [32, 28, 51, 30, 40, 38], [36, 32, 58, 34, 46, 43]])
