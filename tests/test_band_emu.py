@@ -39,6 +39,7 @@ CASES = [
     ("single_mb", 1, 1, 3, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
     ("single_row", 9, 1, 2, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
     ("single_col", 1, 9, 2, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
+    ("wider_than_a_wave", 70, 5, 1, dict(i4x4=0.6, i8x8=0.3), dict(transform_8x8=True)),   # two batches of the mode pre-pass
     ("two_cols", 2, 17, 1, dict(i4x4=0.5, i8x8=0.3), dict(transform_8x8=True)),
     ("all_qp", 10, 8, 2, dict(i4x4=0.5, i8x8=0.3, qp=(0, 51)), dict(transform_8x8=True)),
     ("dense_big_levels", 8, 6, 2, dict(i4x4=0.5, i8x8=0.3, coded=1.0, p0=0.9, decay4=0.97, decay8=0.99, max_level=2047,
