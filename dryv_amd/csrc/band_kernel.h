@@ -125,7 +125,10 @@ constexpr int S_BYTES = (S_CARRYM + 64 + 63) & ~63;
 constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order
 constexpr int S_E8 = S_C8 + 2048;      // [4][128]  BACK: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16,
                                        //           then E1 as bytes (L7..L0, TL at 100..108, T0..T15 at 112..127)
-constexpr int S_G8 = S_E8 + 512;       // T   [4][2 blk8][8][8]  FRONT: row-pass output of the two blocks of a pass (T: 4 bytes; 8 in the
+constexpr int S_F8 = S_E8 + 512;       // u32 [16]  flags between BACK and BACK8: b8Done (BACK8 -> BACK: Intra8x8 macroblocks of step n - 1 are in
+                                       //           the tiles), woDone (BACK -> BACK8: the write-out of step n - 1 is through)
+constexpr int F8_DONE = 0, F8_WO = 4;
+constexpr int S_G8 = S_F8 + 64;        // T   [4][2 blk8][8][8]  FRONT: row-pass output of the two blocks of a pass (T: 4 bytes; 8 in the
                                        //           WIDE build, whose teams are that much larger)
 constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 2048) : S_BYTES; }
 static_assert(S_CARRYM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
@@ -142,6 +145,9 @@ WV int ringy(int ts, int g, int e, int par) {
 #endif
 constexpr int TEAMS_PER_WG = DRYV_BAND_TEAMS;
 constexpr int WAVES_PER_TEAM = 3;  // FRONT, BACK, CHROMA
+// builds that serve the 8x8 transform give a team a fourth wave, BACK8: the Intra8x8 macroblocks of a step (four serial
+// blocks each) next to BACK's Intra4x4 chain instead of behind it
+constexpr int waves_per_team(bool hasI8) { return hasI8 ? 4 : WAVES_PER_TEAM; }
 constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 // wave priorities by role (recon_band.hip); FRONT raises its own for the mode pre-pass of a task, when the other two
 // waves of the team have nothing to do until it is through
@@ -1582,6 +1588,158 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
 // ==================================================================================================================
 // BACK wave: luma prediction and write-out, driven by the records FRONT leaves in LDS
 // ==================================================================================================================
+// top border of macroblock x's luma tile, lane i < 7 of its row group: corner dword of x-1, 16 bytes of x, 8 bytes of x+1
+WV void top_border(int ts, int g, int x, int par, int i) {
+  const int e = i == 0 ? x - 1 : i < 5 ? x : x + 1;
+  const int so = i == 0 ? 12 : i < 5 ? 4 * (i - 1) : 4 * (i - 5);
+  const unsigned v = wv::lds_u32(ringy(ts, g, e, par) + so);
+  wv::lds_st32(tile_of(ts, g, x) + 4 + 16 * (x & 1) + 4 * i, v);
+}
+
+// ---- BACK8 (builds with the 8x8 transform): the Intra8x8 macroblocks of every step ----------------------------------------
+// Same lanes as BACK (16 per row group). Per step it waits for FRONT's record and for BACK's write-out of the step before
+// (left columns, line rings, tile borders), predicts and reconstructs the step's Intra8x8 macroblocks into the tiles
+// while BACK runs the Intra16x16 pass and the Intra4x4 chain on the others (macroblocks of one step never depend on each
+// other), and says so; BACK waits for that before it frees the record and writes the step out.
+WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int ts) {
+  const int lane0 = wv::lane_id();
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  unsigned long long phAcc[BAND_NPH];
+  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
+  unsigned long long phT = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+  const int W = P.W, H = P.H, nF = P.n_frames;
+  BandGeo G = band_geo(0u, nF, W, H);
+  int par = 0;
+  const int lane = lane0;
+  const int g = lane >> 4, i = lane & 15;
+  for (unsigned gstep = 0;; gstep++) {
+    const int buf = (int)(gstep % (unsigned)NBUF);
+    team_wait(ts + S_FLAGS + F_READY + 4 * buf, gstep + 1);
+    const unsigned task = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 16));
+    if (task == TASK_END) break;
+    const int s = wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 20));
+    if (s == 0) {
+      G = band_geo(task, nF, W, H);
+      par = wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 24));
+    }
+    const int resBuf = ts + S_RES + RES_BUF * buf;
+    const int r = G.r0 + g;
+    const bool mbB = r > 0;
+    const int x = s - 2 * g;
+    const bool valid = g < G.nR && (unsigned)x < (unsigned)W;
+    const bool mbA = x > 0;
+    const int slot = x & 1;
+    const int tile = tile_of(ts, g, x);
+    const int kind = (int)(wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g) & 0xffu);
+    PH(0);  // wait for the record
+    if (wv::any(valid && kind == 1)) {
+      team_wait(ts + S_F8 + F8_WO, gstep);
+      PH(1);  // wait for BACK's write-out of the step before
+      if (i < 7 && kind == 1) top_border(ts, g, x, par, i);
+      wv::wave_sync();
+      // ================= luma, Intra8x8 (8.3.2, pred8x8.rs:152-696): four serial blocks ============================
+      // The 16 lanes of a macroblock first build the block's filtered edge E1[0..24] = L7..L0, TL, T0..T15 (8.3.2.2.1,
+      // pred8x8.rs:222-288, incl. quirk Q1), two samples per lane with the neighbours exchanged by DPP, together with the
+      // 3-tap F and 2-tap G of the filtered samples; then every lane predicts four pixels of one row from the per-(mode,
+      // pixel) table (index on the edge, which of E1 / F / G), adds the residual and stores them into the tile.
+      {
+        const bool mine = valid && kind == 1;
+        const int e8 = ts + S_E8 + 128 * g;
+        const unsigned modes4 = wv::lds_u32(ts + S_MSEQ + 96 * buf + 24 * g);
+        const bool mbC = mbB && (x + 1 < P.W);
+        const int py = i >> 1, x0 = 4 * (i & 1);
+        // the four blocks' table entries (mode, pixel) and residuals depend on nothing the chain below produces: requested
+        // up front, so that a block's serial part is two LDS round trips (edge samples, filtered edge), not three
+        unsigned te4s[4];
+        u32x2 rrs[4];
+#pragma unroll
+        for (int b8 = 0; b8 < 4; b8++) {
+          const int m8 = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
+          te4s[b8] = wv::lds_u32(ldsBase + T_T8 + 64 * m8 + 8 * py + x0);
+          rrs[b8] = wv::lds_u64(resBuf + RES_ROW * g + 32 * (4 * (2 * (b8 >> 1) + (py >> 2)) + 2 * (b8 & 1) + (x0 >> 2)) + 8 * (py & 3));
+        }
+#pragma unroll
+        for (int b8 = 0; b8 < 4; b8++) {
+          const int bx = b8 & 1, by = b8 >> 1;
+          const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA, tlAv = topAv && leftAv;
+          const bool trAv = b8 == 0 ? mbB : b8 == 1 ? mbC : b8 == 2;
+          const int mode = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
+          const int org8 = tile + TILE_STRIDE * (8 * by) + 8 + 16 * slot + 8 * bx;  // row y = -1, x = 0 of the block
+          // raw edge samples k = i and k = i + 16 (top-right replaced by T7 when unavailable)
+          auto eaddr = [&](int k) -> int {
+            const int ei = min(k, trAv ? 24 : 16);
+            return ei <= 7 ? org8 + TILE_STRIDE * (8 - ei) - 1 : ei == 8 ? org8 - 1 : org8 + ei - 9;
+          };
+          const int lo = (int)wv::lds_u8(eaddr(i)), hi = (int)wv::lds_u8(eaddr(min(i + 16, 24)));
+          // neighbours along the edge: lane 15's right neighbour is lane 0's second sample and vice versa
+          int lfLo = wv::dpp<DPP_ROW_SHR(1)>(lo, lo);                               // (k = 0 keeps itself)
+          int rtLo = wv::dpp<DPP_ROW_SHL(1)>(wv::dppx<DPP_ROW_ROR(15)>(hi), lo);
+          int lfHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(lo), hi);
+          int rtHi = wv::dpp<DPP_ROW_SHL(1)>(hi, hi);
+          if (i >= 8) rtHi = hi;                                                    // k >= 24: no right neighbour
+          if (i == 8) {                                                             // the corner
+            if (!leftAv) lfLo = lo;
+            if (!topAv) rtLo = lo;
+          }
+          if (i == 9 && !tlAv) lfLo = -1;  // Q1: p[-1,-1] = -1 enters the x = 0 filter tap
+          if (i == 7 && !tlAv) rtLo = lo;
+          const int e1Lo = (lfLo + 2 * lo + rtLo + 2) >> 2, e1Hi = (lfHi + 2 * hi + rtHi + 2) >> 2;
+          const int elLo = wv::dpp<DPP_ROW_SHR(1)>(e1Lo, e1Lo);
+          const int erLo = wv::dpp<DPP_ROW_SHL(1)>(wv::dppx<DPP_ROW_ROR(15)>(e1Hi), e1Lo);
+          const int elHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(e1Lo), e1Hi);
+          int erHi = wv::dpp<DPP_ROW_SHL(1)>(e1Hi, e1Hi);
+          if (i >= 8) erHi = e1Hi;
+          const unsigned pkLo = ((unsigned)e1Lo & 0xffu) | ((((unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2) & 0xffu) << 8) |
+                                ((((unsigned)(e1Lo + erLo + 1) >> 1) & 0xffu) << 16);
+          const unsigned pkHi = ((unsigned)e1Hi & 0xffu) | ((((unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2) & 0xffu) << 8) |
+                                ((((unsigned)(e1Hi + erHi + 1) >> 1) & 0xffu) << 16);
+          wv::lds_st32(e8 + 4 * i, pkLo);
+          wv::lds_st8(e8 + 100 + (i <= 8 ? i : i + 3), (unsigned)e1Lo);
+          if (i <= 8) {
+            wv::lds_st32(e8 + 4 * (i + 16), pkHi);
+            wv::lds_st8(e8 + 100 + i + 19, (unsigned)e1Hi);
+          }
+          wv::wave_sync();
+          // four pixels of row py: x0 .. x0 + 3
+          const unsigned te4 = te4s[b8];
+          unsigned pr[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const unsigned te = (te4 >> (8 * q)) & 0xffu;
+            const unsigned w = wv::lds_u32(e8 + 4 * (int)(te & 31u));
+            pr[q] = (w >> (8 * (te >> 5))) & 0xffu;
+          }
+          {
+            const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | (tlAv ? 4 : 0);
+            const int req = (int)((0x217771021ull >> (4 * mode)) & 7ull);
+            if ((req & ~have) != 0) pr[0] = pr[1] = pr[2] = pr[3] = 0;   // quirk Q4
+            if (mode == 2) {  // DC (pred8x8.rs:350-394)
+              const int sumL = (int)wv::sad4(wv::lds_u32(e8 + 100)) + (int)wv::sad4(wv::lds_u32(e8 + 104));
+              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 112)) + (int)wv::sad4(wv::lds_u32(e8 + 116));
+              const int dc = (topAv && leftAv) ? (sumT + sumL + 8) >> 4 : leftAv ? (sumL + 4) >> 3 : topAv ? (sumT + 4) >> 3 : 128;
+              pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
+            }
+          }
+          const u32x2 rr = rrs[b8];
+          const unsigned o = recon_row(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16), rr.x, rr.y);
+          if (mine) wv::lds_st32(org8 + TILE_STRIDE * (py + 1) + x0, o);
+          wv::wave_sync();
+        }
+      }
+
+      PH(2);  // Intra8x8
+    }
+    wv::wave_sync();
+    if (lane == 0) wv::lds_st32(ts + S_F8 + F8_DONE, gstep + 1);
+  }
+#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
+  if (lane0 == 0 && A.profile)
+    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
+#endif
+}
+
 template <bool HAS_I8>
 WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
@@ -1639,7 +1797,8 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     // (the bottom luma lines of the band above are in row 0's ring: FRONT fetched them)
     // top border of the luma tile: corner dword of x-1, 16 bytes of x, 8 bytes of x+1 (the top-right neighbour: its
     // row above finished it in the previous step, or FRONT fetched it with this step's record)
-    if (i < 7) {
+    // (an Intra8x8 macroblock's border is copied by BACK8, which predicts it)
+    if (i < 7 && !(HAS_I8 && kind == 1)) {
       const int e = i == 0 ? x - 1 : i < 5 ? x : x + 1;
       const int so = i == 0 ? 12 : i < 5 ? 4 * (i - 1) : 4 * (i - 5);
       const unsigned v = wv::lds_u32(ringy(ts, g, e, par) + so);
@@ -1858,95 +2017,10 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 #undef I4_BODY
       }
 
-      // ================= luma, Intra8x8 (8.3.2, pred8x8.rs:152-696): four serial blocks ============================
-      // The 16 lanes of a macroblock first build the block's filtered edge E1[0..24] = L7..L0, TL, T0..T15 (8.3.2.2.1,
-      // pred8x8.rs:222-288, incl. quirk Q1), two samples per lane with the neighbours exchanged by DPP, together with the
-      // 3-tap F and 2-tap G of the filtered samples; then every lane predicts four pixels of one row from the per-(mode,
-      // pixel) table (index on the edge, which of E1 / F / G), adds the residual and stores them into the tile.
-      if (HAS_I8 && wv::any(valid && kind == 1)) {
-        const bool mine = valid && kind == 1;
-        const int e8 = ts + S_E8 + 128 * g;
-        const unsigned modes4 = wv::lds_u32(ts + S_MSEQ + 96 * buf + 24 * g);
-        const bool mbC = mbB && (x + 1 < P.W);
-        const int py = i >> 1, x0 = 4 * (i & 1);
-        // the four blocks' table entries (mode, pixel) and residuals depend on nothing the chain below produces: requested
-        // up front, so that a block's serial part is two LDS round trips (edge samples, filtered edge), not three
-        unsigned te4s[4];
-        u32x2 rrs[4];
-#pragma unroll
-        for (int b8 = 0; b8 < 4; b8++) {
-          const int m8 = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
-          te4s[b8] = wv::lds_u32(ldsBase + T_T8 + 64 * m8 + 8 * py + x0);
-          rrs[b8] = wv::lds_u64(resBuf + RES_ROW * g + 32 * (4 * (2 * (b8 >> 1) + (py >> 2)) + 2 * (b8 & 1) + (x0 >> 2)) + 8 * (py & 3));
-        }
-#pragma unroll
-        for (int b8 = 0; b8 < 4; b8++) {
-          const int bx = b8 & 1, by = b8 >> 1;
-          const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA, tlAv = topAv && leftAv;
-          const bool trAv = b8 == 0 ? mbB : b8 == 1 ? mbC : b8 == 2;
-          const int mode = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
-          const int org8 = tile + TILE_STRIDE * (8 * by) + 8 + 16 * slot + 8 * bx;  // row y = -1, x = 0 of the block
-          // raw edge samples k = i and k = i + 16 (top-right replaced by T7 when unavailable)
-          auto eaddr = [&](int k) -> int {
-            const int ei = min(k, trAv ? 24 : 16);
-            return ei <= 7 ? org8 + TILE_STRIDE * (8 - ei) - 1 : ei == 8 ? org8 - 1 : org8 + ei - 9;
-          };
-          const int lo = (int)wv::lds_u8(eaddr(i)), hi = (int)wv::lds_u8(eaddr(min(i + 16, 24)));
-          // neighbours along the edge: lane 15's right neighbour is lane 0's second sample and vice versa
-          int lfLo = wv::dpp<DPP_ROW_SHR(1)>(lo, lo);                               // (k = 0 keeps itself)
-          int rtLo = wv::dpp<DPP_ROW_SHL(1)>(wv::dppx<DPP_ROW_ROR(15)>(hi), lo);
-          int lfHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(lo), hi);
-          int rtHi = wv::dpp<DPP_ROW_SHL(1)>(hi, hi);
-          if (i >= 8) rtHi = hi;                                                    // k >= 24: no right neighbour
-          if (i == 8) {                                                             // the corner
-            if (!leftAv) lfLo = lo;
-            if (!topAv) rtLo = lo;
-          }
-          if (i == 9 && !tlAv) lfLo = -1;  // Q1: p[-1,-1] = -1 enters the x = 0 filter tap
-          if (i == 7 && !tlAv) rtLo = lo;
-          const int e1Lo = (lfLo + 2 * lo + rtLo + 2) >> 2, e1Hi = (lfHi + 2 * hi + rtHi + 2) >> 2;
-          const int elLo = wv::dpp<DPP_ROW_SHR(1)>(e1Lo, e1Lo);
-          const int erLo = wv::dpp<DPP_ROW_SHL(1)>(wv::dppx<DPP_ROW_ROR(15)>(e1Hi), e1Lo);
-          const int elHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(e1Lo), e1Hi);
-          int erHi = wv::dpp<DPP_ROW_SHL(1)>(e1Hi, e1Hi);
-          if (i >= 8) erHi = e1Hi;
-          const unsigned pkLo = ((unsigned)e1Lo & 0xffu) | ((((unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2) & 0xffu) << 8) |
-                                ((((unsigned)(e1Lo + erLo + 1) >> 1) & 0xffu) << 16);
-          const unsigned pkHi = ((unsigned)e1Hi & 0xffu) | ((((unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2) & 0xffu) << 8) |
-                                ((((unsigned)(e1Hi + erHi + 1) >> 1) & 0xffu) << 16);
-          wv::lds_st32(e8 + 4 * i, pkLo);
-          wv::lds_st8(e8 + 100 + (i <= 8 ? i : i + 3), (unsigned)e1Lo);
-          if (i <= 8) {
-            wv::lds_st32(e8 + 4 * (i + 16), pkHi);
-            wv::lds_st8(e8 + 100 + i + 19, (unsigned)e1Hi);
-          }
-          wv::wave_sync();
-          // four pixels of row py: x0 .. x0 + 3
-          const unsigned te4 = te4s[b8];
-          unsigned pr[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const unsigned te = (te4 >> (8 * q)) & 0xffu;
-            const unsigned w = wv::lds_u32(e8 + 4 * (int)(te & 31u));
-            pr[q] = (w >> (8 * (te >> 5))) & 0xffu;
-          }
-          {
-            const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | (tlAv ? 4 : 0);
-            const int req = (int)((0x217771021ull >> (4 * mode)) & 7ull);
-            if ((req & ~have) != 0) pr[0] = pr[1] = pr[2] = pr[3] = 0;   // quirk Q4
-            if (mode == 2) {  // DC (pred8x8.rs:350-394)
-              const int sumL = (int)wv::sad4(wv::lds_u32(e8 + 100)) + (int)wv::sad4(wv::lds_u32(e8 + 104));
-              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 112)) + (int)wv::sad4(wv::lds_u32(e8 + 116));
-              const int dc = (topAv && leftAv) ? (sumT + sumL + 8) >> 4 : leftAv ? (sumL + 4) >> 3 : topAv ? (sumT + 4) >> 3 : 128;
-              pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
-            }
-          }
-          const u32x2 rr = rrs[b8];
-          const unsigned o = recon_row(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16), rr.x, rr.y);
-          if (mine) wv::lds_st32(org8 + TILE_STRIDE * (py + 1) + x0, o);
-          wv::wave_sync();
-        }
-      }
+      // (builds with the 8x8 transform: the step's Intra8x8 macroblocks are BACK8's, which worked next to the chain)
+      // (at least: BACK8 may already be through a next step that has none)
+      if (HAS_I8) team_wait_ge(ts + S_F8 + F8_DONE, gstep + 1);
+      PH(6);  // wait for BACK8
 
       // the record has been consumed
       wv::wave_sync();
@@ -1992,6 +2066,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         }
       }
       wv::wave_sync();
+      if (HAS_I8 && lane == 0) wv::lds_st32(ts + S_F8 + F8_WO, gstep + 1);  // BACK8 may start the next step
       PH(5);  // line, copies, flush
       // the band's luma is complete once its last stores have been written through
       if (s == G.nSteps - 1 && hasBelow) {

@@ -23,24 +23,26 @@ namespace dryv {
 #define DRYV_BAND_WGS_PER_CU_I8 5
 #endif
 template <bool HAS_I8, bool WIDE>
-__global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? DRYV_BAND_WPS_I8 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
+__global__ void __launch_bounds__(64 * ((HAS_I8 || WIDE) ? 4 : band::WAVES_PER_WG), WIDE ? 4 : HAS_I8 ? DRYV_BAND_WPS_I8 : DRYV_BAND_WPS) band_kernel(const KParams P, band::Args A) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds[];
   const int ldsBase = (int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   constexpr int tEnd = HAS_I8 ? band::T_END_I8 : band::T_END;
   A.waveBase = (int)blockIdx.x * band::WAVES_PER_WG;
   band::build_tables(P, ldsBase, (int)threadIdx.x, (int)blockDim.x, HAS_I8);
-  if (threadIdx.x < 64 * (blockDim.x / (64 * band::WAVES_PER_TEAM))) {
+  constexpr int WPT = band::waves_per_team(HAS_I8);
+  if (threadIdx.x < 64 * (blockDim.x / (64 * WPT))) {
     // the teams' flag words (16), and the table-row bytes of the block chain (24 words per queued record): some are never
     // written (the second block half has no block in four of the ten rounds) and must still be offsets of table rows
     const int q = (int)(threadIdx.x & 63);
     const int tsq = ldsBase + tEnd + (int)(threadIdx.x >> 6) * band::team_bytes(HAS_I8, WIDE);
     if (q < 16) wv::lds_st32(tsq + band::S_FLAGS + 4 * q, 0u);
+    if (HAS_I8 && q < 16) wv::lds_st32(tsq + band::S_F8 + 4 * q, 0u);
     for (int k = q; k < 24 * band::NBUF; k += 64) wv::lds_st32(tsq + band::S_MSEQ + 4 * k, 0u);
   }
   __syncthreads();  // the only workgroup-level synchronisation: the teams are independent from here on
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // consecutive waves of a workgroup go to different SIMDs: a team's three waves never share one
-  const int team = wave / band::WAVES_PER_TEAM, role = wave - team * band::WAVES_PER_TEAM;
+  const int team = wave / WPT, role = wave - team * WPT;
   const int ts = ldsBase + tEnd + team * band::team_bytes(HAS_I8, WIDE);
   // Wave priority by role (s_setprio: the SIMD's arbiter prefers the higher one when several waves can issue). FRONT is a
   // producer that runs up to two steps ahead of the other two; BACK is the wave on a band's critical path, and CHROMA's
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? D
   // batch (tools/band_variants.sh, same box within a line): no priorities 1.444 ms / BACK 2: 1.388 / BACK 3: 1.397;
   // BACK 2: 1.433 / BACK 2 + CHROMA 1: 1.373 / BACK = CHROMA = 2: 1.336-1.370 / 1, 1: 1.335-1.371 / 3, 2: 1.335-1.370;
   // FRONT raised with them, or alone: 1.47-1.49 (no gain or worse).
-  if (role == 1 && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
+  if ((role == 1 || (HAS_I8 && role == 3)) && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
   if (role == 2 && DRYV_BAND_PRIO_CHROMA) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_CHROMA);
   if (role == 0 && DRYV_BAND_PRIO_FRONT) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_FRONT);
 #ifdef DRYV_BAND_ONLY_ROLE   // analysis only (tools/resource_usage.py): the registers one role needs when compiled alone
@@ -56,6 +58,7 @@ __global__ void __launch_bounds__(64 * band::WAVES_PER_WG, WIDE ? 4 : HAS_I8 ? D
 #endif
   if (role == 1) band::band_back<HAS_I8>(P, A, ldsBase, ts);
   else if (role == 0) band::band_front<HAS_I8, WIDE>(P, A, ldsBase, ts);
+  else if (HAS_I8 && role == 3) band::band_back8(P, A, ldsBase, ts);
   else band::band_chroma<HAS_I8, WIDE>(P, A, ldsBase, ts);
 }
 
@@ -106,7 +109,7 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   const bool i8 = P.transform8x8 != 0;
   const int teams = band_teams_per_block(i8, wide);
   const size_t ldsBytes = band_lds_bytes(i8, wide, teams);
-  const dim3 g(grid), b(64 * band::WAVES_PER_TEAM * teams);
+  const dim3 g(grid), b(64 * band::waves_per_team(i8) * teams);
   if (ldsBytes > 65536) {  // (build variants with wide staging: beyond the default dynamic LDS limit)
     const void* fn = i8 ? (wide ? (const void*)band_kernel<true, true> : (const void*)band_kernel<true, false>)
                         : (wide ? (const void*)band_kernel<false, true> : (const void*)band_kernel<false, false>);

@@ -96,10 +96,12 @@ static bool g_wide;
 static int wave_index() { return wv::g_wave->index; }
 static void body() {
   using namespace dryv::band;
-  const int role = wave_index() % WAVES_PER_TEAM;  // waves 3t .. 3t+2 = FRONT / BACK / CHROMA of team t (each team has its own LDS here)
   const bool i8 = g_P.transform8x8 != 0;
+  const int role = wave_index() % waves_per_team(i8);  // FRONT / BACK / CHROMA (/ BACK8) of team t (each team has its own LDS here)
   const int ts = i8 ? T_END_I8 : T_END;
-  if (role == 1) {
+  if (role == 3) {
+    band_back8(g_P, g_A, 0, ts);
+  } else if (role == 1) {
     if (i8) band_back<true>(g_P, g_A, 0, ts);
     else band_back<false>(g_P, g_A, 0, ts);
   } else if (role == 2) {
@@ -127,7 +129,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
   int st = dryv::params::build_params(fp, n_frames, &g_P);
   if (st != DRYV_OK) return st;
   if (n_teams < 1) n_teams = 1;
-  const int WPT = dryv::band::WAVES_PER_TEAM;
+  const int WPT = dryv::band::waves_per_team(g_P.transform8x8 != 0);
   const int n_waves = WPT * n_teams;
   const int nBands = (g_P.H + 3) / 4;
   std::vector<unsigned> prog((size_t)3 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H * dryv::band::MREC_WORDS, 0xEEEEEEEEu);
@@ -154,6 +156,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
       if (w % WPT == 0) {
         dryv::band::build_tables(g_P, 0, 0, 1, g_P.transform8x8 != 0);
         memset(teamLds[w / WPT].data() + ldsBytes - teamBytes + dryv::band::S_FLAGS, 0, 64);  // the team's flags
+        if (g_P.transform8x8) memset(teamLds[w / WPT].data() + ldsBytes - teamBytes + dryv::band::S_F8, 0, 64);
         memset(teamLds[w / WPT].data() + ldsBytes - teamBytes + dryv::band::S_MSEQ, 0, 96 * dryv::band::NBUF);  // (as the kernel's prologue does)
       }
     }
@@ -167,7 +170,12 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
         unsigned long long t = 0;
         for (unsigned v : prog) t += v;
         for (auto& L : teamLds)
-          for (int q = 0; q < 64; q += 4) { unsigned v; memcpy(&v, L.data() + ldsBytes - teamBytes + dryv::band::S_FLAGS + q, 4); t += v; }
+          for (int q = 0; q < 64; q += 4) {
+            unsigned v;
+            memcpy(&v, L.data() + ldsBytes - teamBytes + dryv::band::S_FLAGS + q, 4);
+            t += v;
+            if (g_P.transform8x8) { memcpy(&v, L.data() + ldsBytes - teamBytes + dryv::band::S_F8 + q, 4); t += v; }
+          }
         return t;
       };
       const unsigned long long sum0 = progress();
