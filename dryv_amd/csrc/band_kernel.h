@@ -72,7 +72,7 @@ constexpr int T_QP = 3072;    // u32 [52][8]    per qp, what a 4x4 residual pass
                               //                [6] rounding term and [7] shl | shr << 8 of the Intra16x16 DC scaling
 constexpr int T_END = 4736;
 constexpr int T_LS8 = T_END;          // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
-constexpr int T_T8 = T_LS8 + 768;     // u8  [9][64]    Intra8x8 table [mode][y*8+x]: index on the filtered edge | value kind << 5
+constexpr int T_T8 = T_LS8 + 768;     // u8  [9][64]    Intra8x8 table [mode][y*8+x]: byte offset of the sample in S_E8 (32 * which of E1 / F / G + position)
 constexpr int T_ZZ8 = T_T8 + 576;     // u8  [64]       8x8 list index -> 2 * raster position
 constexpr int T_END_I8 = T_ZZ8 + 64;
 static_assert(T_END % 64 == 0 && T_END_I8 % 64 == 0, "table layout");
@@ -123,8 +123,8 @@ constexpr int S_CARRYM = S_LEFTC + 64;            // u32 [4]     mode pre-pass: 
 constexpr int S_BYTES = (S_CARRYM + 64 + 63) & ~63;
 // builds that serve the 8x8 transform (HAS_I8) append, per team:
 constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order
-constexpr int S_E8 = S_C8 + 2048;      // [4][128]  BACK: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16,
-                                       //           then E1 as bytes (L7..L0, TL at 100..108, T0..T15 at 112..127)
+constexpr int S_E8 = S_C8 + 2048;      // [4][128]  BACK8: the filtered edge of the current 8x8 block, bytes: E1 at 0 (L7..L0, TL at 0..8, T0..T15 at
+                                       //           12..27), its 3-tap F at 32, its 2-tap G at 64
 constexpr int S_F8 = S_E8 + 512;       // u32 [16]  flags between BACK and BACK8: b8Done (BACK8 -> BACK: Intra8x8 macroblocks of step n - 1 are in
                                        //           the tiles), woDone (BACK -> BACK8: the write-out of step n - 1 is through)
 constexpr int F8_DONE = 0, F8_WO = 4;
@@ -315,7 +315,11 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
   }
   if (hasI8) {
     for (int k = tid; k < 384; k += nthreads) wv::lds_st16(ldsBase + T_LS8 + 2 * k, P.ls8[k]);
-    for (int k = tid; k < 576; k += nthreads) wv::lds_st8(ldsBase + T_T8 + k, P.t8[k]);
+    for (int k = tid; k < 576; k += nthreads) {
+      // index on the edge | which of E1 / F / G << 5 -> byte offset in BACK8's edge arrays (S_E8): the top samples sit 3 further
+      const int e = P.t8[k], idx = e & 31;
+      wv::lds_st8(ldsBase + T_T8 + k, (unsigned)((e & ~31) + (idx <= 8 ? idx : idx + 3)));
+    }
     for (int k = tid; k < 64; k += nthreads) wv::lds_st8(ldsBase + T_ZZ8 + P.zz8i[k], (unsigned)(2 * k));
   }
 }
@@ -608,12 +612,17 @@ WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts,
           dd[k] = (T)(long long)(((unsigned long long)v.y << 32) | v.x);
         }
       }
+      dd[0] += (T)32;   // the rounding term of (x + 32) >> 6: d0 enters every output of the 8-point transform once, unscaled
       idct8<T>(dd, oo);
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        const T lo = (T)-32768, hi = (T)32767;
-        const int a = (int)min(max((oo[2 * m] + 32) >> 6, lo), hi), b = (int)min(max((oo[2 * m + 1] + 32) >> 6, lo), hi);
-        out[4 * p + m] = ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+        if (sizeof(T) == 4) {
+          out[4 * p + m] = wv::cvt_pk_i16((int)(oo[2 * m] >> 6), (int)(oo[2 * m + 1] >> 6));   // (saturating)
+        } else {
+          const T lo = (T)-32768, hi = (T)32767;
+          const int a = (int)min(max(oo[2 * m] >> 6, lo), hi), b = (int)min(max(oo[2 * m + 1] >> 6, lo), hi);
+          out[4 * p + m] = ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+        }
       }
     }
     wv::wave_sync();  // (S_G8 is reused by the next pass)
@@ -1691,33 +1700,29 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
           const int elHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(e1Lo), e1Hi);
           int erHi = wv::dpp<DPP_ROW_SHL(1)>(e1Hi, e1Hi);
           if (i >= 8) erHi = e1Hi;
-          const unsigned pkLo = ((unsigned)e1Lo & 0xffu) | ((((unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2) & 0xffu) << 8) |
-                                ((((unsigned)(e1Lo + erLo + 1) >> 1) & 0xffu) << 16);
-          const unsigned pkHi = ((unsigned)e1Hi & 0xffu) | ((((unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2) & 0xffu) << 8) |
-                                ((((unsigned)(e1Hi + erHi + 1) >> 1) & 0xffu) << 16);
-          wv::lds_st32(e8 + 4 * i, pkLo);
-          wv::lds_st8(e8 + 100 + (i <= 8 ? i : i + 3), (unsigned)e1Lo);
+          // three byte arrays, 32 bytes apart: E1, F, G at position k (k <= 8) / k + 3 (the top samples: T0 dword-aligned)
+          const int kLo = e8 + (i <= 8 ? i : i + 3);
+          wv::lds_st8(kLo, (unsigned)e1Lo);
+          wv::lds_st8(kLo + 32, (unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2);
+          wv::lds_st8(kLo + 64, (unsigned)(e1Lo + erLo + 1) >> 1);
           if (i <= 8) {
-            wv::lds_st32(e8 + 4 * (i + 16), pkHi);
-            wv::lds_st8(e8 + 100 + i + 19, (unsigned)e1Hi);
+            wv::lds_st8(e8 + i + 19, (unsigned)e1Hi);
+            wv::lds_st8(e8 + i + 19 + 32, (unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2);
+            wv::lds_st8(e8 + i + 19 + 64, (unsigned)(e1Hi + erHi + 1) >> 1);
           }
           wv::wave_sync();
-          // four pixels of row py: x0 .. x0 + 3
+          // four pixels of row py: x0 .. x0 + 3; a table entry is the sample's byte offset in those arrays
           const unsigned te4 = te4s[b8];
           unsigned pr[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const unsigned te = (te4 >> (8 * q)) & 0xffu;
-            const unsigned w = wv::lds_u32(e8 + 4 * (int)(te & 31u));
-            pr[q] = (w >> (8 * (te >> 5))) & 0xffu;
-          }
+          for (int q = 0; q < 4; q++) pr[q] = wv::lds_u8(e8 + (int)((te4 >> (8 * q)) & 0xffu));
           {
             const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | (tlAv ? 4 : 0);
             const int req = (int)((0x217771021ull >> (4 * mode)) & 7ull);
             if ((req & ~have) != 0) pr[0] = pr[1] = pr[2] = pr[3] = 0;   // quirk Q4
             if (mode == 2) {  // DC (pred8x8.rs:350-394)
-              const int sumL = (int)wv::sad4(wv::lds_u32(e8 + 100)) + (int)wv::sad4(wv::lds_u32(e8 + 104));
-              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 112)) + (int)wv::sad4(wv::lds_u32(e8 + 116));
+              const int sumL = (int)wv::sad4(wv::lds_u32(e8)) + (int)wv::sad4(wv::lds_u32(e8 + 4));
+              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 12)) + (int)wv::sad4(wv::lds_u32(e8 + 16));
               const int dc = (topAv && leftAv) ? (sumT + sumL + 8) >> 4 : leftAv ? (sumL + 4) >> 3 : topAv ? (sumT + 4) >> 3 : 128;
               pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
             }
@@ -2017,15 +2022,15 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 #undef I4_BODY
       }
 
+      PH(4);  // Intra4x4 chain
       // (builds with the 8x8 transform: the step's Intra8x8 macroblocks are BACK8's, which worked next to the chain)
       // (at least: BACK8 may already be through a next step that has none)
       if (HAS_I8) team_wait_ge(ts + S_F8 + F8_DONE, gstep + 1);
-      PH(6);  // wait for BACK8
 
       // the record has been consumed
       wv::wave_sync();
       if (lane == 0) wv::lds_st32(ts + S_FLAGS + F_FREE + 4 * buf, gstep + 1);
-      PH(4);  // Intra4x4 chain
+      PH(6);  // wait for BACK8, record freed
 
       // ================= luma write-out ============================================================================
       EXP_REP(11) {

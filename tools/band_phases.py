@@ -17,13 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dryv_amd import _build, abi, synth  # noqa: E402
 
-ROLES = ["FRONT", "BACK", "CHROMA"]   # wave w of a workgroup: role w % 3 (recon_band.hip)
+ROLES = ["FRONT", "BACK", "CHROMA", "BACK8"]   # wave w of a team: role w % 3 (w % 4 in builds with the 8x8 transform; recon_band.hip)
 PHASES = {
     "FRONT": ["claim+prologue", "record decode", "luma residuals", "hand-off+prefetch", "record for BACK (incl. wait for a free buffer)",
               "-", "wait for the mode pre-pass (per task, here per step)"],
     "CHROMA": ["task+prologue", "hand-off traffic", "chroma residuals+prefetch", "chroma prediction", "lines+copies+flush",
                "mode pre-pass of the task (here per step)"],
-    "BACK": ["wait for record", "top border", "intra16x16", "top-right+publish", "intra4x4 chain", "line+copies+flush"],
+    "BACK": ["wait for record", "top border", "intra16x16", "top-right+publish", "intra4x4 chain", "line+copies+flush",
+             "wait for BACK8"],
+    "BACK8": ["wait for record", "wait for BACK's write-out of the step before", "top border + four Intra8x8 blocks"],
 }
 
 
@@ -61,8 +63,10 @@ def main():
         steps = tasks * (fp.pic_width_in_mbs + 6.0)
         print("== %d frames: instrumented kernel %.3f ms, %d band tasks" % (frames, ms.value, tasks))
         wave = np.arange(n_waves)
-        for ri, role in enumerate(ROLES):
-            tot = out[(wave % wpw) % 3 == ri].sum(axis=0).astype(np.float64)
+        i8 = bool(fp.transform_8x8_mode_flag)
+        for ri, role in enumerate(ROLES[:4 if i8 else 3]):
+            # (builds with the 8x8 transform: one team of four waves per workgroup, in a 12-wave index space)
+            tot = out[(wave % 12) == ri if i8 else (wave % wpw) % 3 == ri].sum(axis=0).astype(np.float64)
             print("  %s: %.0f cycles/step" % (role, tot.sum() / steps))
             for name, v in zip(PHASES[role], tot):
                 print("      %-30s %8.0f" % (name, v / steps))

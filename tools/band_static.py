@@ -9,7 +9,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DD
        "-S", "--cuda-device-only", "-o", out, "%s/dryv_amd/csrc/recon_band.hip" % root] + sys.argv[1:]
 subprocess.check_call(cmd)
 lines = open(out).read().split("\n")
-start = [i for i, l in enumerate(lines) if l.startswith("_ZN4dryv11band_kernelILb0ELb0E")][0]
+start = [i for i, l in enumerate(lines) if l.startswith(os.environ.get("BAND_SYM", "_ZN4dryv11band_kernelILb0ELb0E"))][0]
 end = [i for i, l in enumerate(lines) if i > start and "s_endpgm" in l][0]
 src = open("%s/dryv_amd/csrc/band_kernel.h" % root).read().split("\n")
 cur = "prologue"
