@@ -160,6 +160,12 @@ constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 #ifndef DRYV_BAND_PRIO_FRONT
 #define DRYV_BAND_PRIO_FRONT 0
 #endif
+#ifndef DRYV_BAND_PRIO_FRONT_I8   // (builds with the 8x8 transform, where FRONT carries the 8x8 residuals as well: measured 0 = 1
+#define DRYV_BAND_PRIO_FRONT_I8 DRYV_BAND_PRIO_FRONT   //  < 2 (+2.8 %) < 3 (+18 %) on the 4K batch)
+#endif
+#ifndef DRYV_BAND_PRIO_BACK8      // (0: +2.6 %)
+#define DRYV_BAND_PRIO_BACK8 DRYV_BAND_PRIO_BACK
+#endif
 #ifndef DRYV_BAND_PRIO_MODES
 #define DRYV_BAND_PRIO_MODES 3
 #endif

@@ -50,9 +50,10 @@ __global__ void __launch_bounds__(64 * ((HAS_I8 || WIDE) ? 4 : band::WAVES_PER_W
   // batch (tools/band_variants.sh, same box within a line): no priorities 1.444 ms / BACK 2: 1.388 / BACK 3: 1.397;
   // BACK 2: 1.433 / BACK 2 + CHROMA 1: 1.373 / BACK = CHROMA = 2: 1.336-1.370 / 1, 1: 1.335-1.371 / 3, 2: 1.335-1.370;
   // FRONT raised with them, or alone: 1.47-1.49 (no gain or worse).
-  if ((role == 1 || (HAS_I8 && role == 3)) && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
+  if (role == 1 && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
+  if (HAS_I8 && role == 3 && DRYV_BAND_PRIO_BACK8) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK8);
   if (role == 2 && DRYV_BAND_PRIO_CHROMA) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_CHROMA);
-  if (role == 0 && DRYV_BAND_PRIO_FRONT) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_FRONT);
+  if (role == 0 && (HAS_I8 ? DRYV_BAND_PRIO_FRONT_I8 : DRYV_BAND_PRIO_FRONT)) __builtin_amdgcn_s_setprio(HAS_I8 ? DRYV_BAND_PRIO_FRONT_I8 : DRYV_BAND_PRIO_FRONT);
 #ifdef DRYV_BAND_ONLY_ROLE   // analysis only (tools/resource_usage.py): the registers one role needs when compiled alone
   if (role != DRYV_BAND_ONLY_ROLE) return;
 #endif
