@@ -1,4 +1,5 @@
-// band_kernel.h — macroblock reconstruction, one TEAM of three wavefronts per band of four macroblock rows (gfx950).
+// band_kernel.h — macroblock reconstruction, one TEAM of three wavefronts (four in builds with the 8x8 transform) per band of
+// four macroblock rows (gfx950).
 // The one reconstruction kernel of the library: every stream (with or without the 8x8 transform; fast and WIDE builds).
 //
 // Decomposition
@@ -9,8 +10,12 @@
 //   * A band is worked on by a team of three waves of one workgroup that run on different SIMDs:
 //       FRONT   the step's record for BACK: luma residuals (into a queue of records in LDS), the step's slice of the
 //               band's mode records, and the fetch of the band above's bottom luma lines;
-//       BACK    luma prediction (Intra16x16, the Intra4x4 block wavefront, Intra8x8), luma staging, stores: the only wave
-//               on the frame's critical path, and it never touches global memory except to store;
+//       BACK    luma prediction (Intra16x16, the Intra4x4 block wavefront), luma staging, stores: the wave on the frame's
+//               critical path, and it never touches global memory except to store;
+//       BACK8   (builds with the 8x8 transform only) the step's Intra8x8 macroblocks -- four serial 8x8 blocks each --
+//               next to BACK's Intra4x4 chain instead of behind it: macroblocks of one step never depend on each
+//               other. Two more LDS words: BACK8 -> BACK "the step's Intra8x8 macroblocks are in the tiles", BACK ->
+//               BACK8 "the step's write-out (left columns, line rings, tile borders) is through";
 //       CHROMA  all of chroma (residuals, prediction, staging, stores, hand-off): nothing in it depends on a luma
 //               pixel or on the other two waves -- and, between two tasks, the next band's prediction modes (band_modes:
 //               a pre-pass over the whole band, one lane per macroblock).
@@ -72,9 +77,15 @@ constexpr int T_QP = 3072;    // u32 [52][8]    per qp, what a 4x4 residual pass
                               //                [6] rounding term and [7] shl | shr << 8 of the Intra16x16 DC scaling
 constexpr int T_END = 4736;
 constexpr int T_LS8 = T_END;          // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
-constexpr int T_T8 = T_LS8 + 768;     // u8  [9][64]    Intra8x8 table [mode][y*8+x]: byte offset of the sample in S_E8 (32 * which of E1 / F / G + position)
+constexpr int T_T8 = T_LS8 + 768;     // u8  [9][64]    Intra8x8 table [mode][y*8+x]: byte offset of the sample in S_E8 (4 * position + which of E1 / F / G)
 constexpr int T_ZZ8 = T_T8 + 576;     // u8  [64]       8x8 list index -> 2 * raster position
-constexpr int T_END_I8 = T_ZZ8 + 64;
+// the packed 16-bit form of the 8x8 residual (residual8x8_pk16): a lane works on rows 2p (low halves) and 2p + 1 (high halves)
+constexpr int T_LS8P = T_ZZ8 + 64;    // u32 [6][4][8]  LevelScale8x8 of (row 2p, column j) | (row 2p + 1, column j) << 16
+constexpr int T_ZZ8P = T_LS8P + 768;  // u8  [64]       8x8 list index -> byte offset of (row, column) in the pair-interleaved block:
+                                      //                32 * (row >> 1) + 4 * column + 2 * (row & 1)
+constexpr int T_THR8P = T_ZZ8P + 64;  // u16 [52]       per qp: the largest sum of |coefficients| of an 8x8 block for which the packed form is
+                                      //                exact (0: none)
+constexpr int T_END_I8 = T_THR8P + 128;
 static_assert(T_END % 64 == 0 && T_END_I8 % 64 == 0, "table layout");
 
 // ---- per-team scratch in LDS (byte offsets from the team's base) ---------------------------------------------
@@ -122,15 +133,20 @@ constexpr int S_LEFTC = S_RINGC + 256;            // u8 [4][2][8]
 constexpr int S_CARRYM = S_LEFTC + 64;            // u32 [4]     mode pre-pass: right-column modes of the macroblock left of the batch, per row
 constexpr int S_BYTES = (S_CARRYM + 64 + 63) & ~63;
 // builds that serve the 8x8 transform (HAS_I8) append, per team:
-constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order
-constexpr int S_E8 = S_C8 + 2048;      // [4][128]  BACK8: the filtered edge of the current 8x8 block, bytes: E1 at 0 (L7..L0, TL at 0..8, T0..T15 at
-                                       //           12..27), its 3-tap F at 32, its 2-tap G at 64
+constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order (the packed form:
+                                       //           pair-interleaved, T_ZZ8P); a block every C8_BLK bytes, a macroblock every C8_MB: the
+                                       //           lanes that address their blocks alike land 4 banks apart (a 128-byte stride put the
+                                       //           eight of a 32-lane group on ONE bank)
+constexpr int C8_BLK = 144, C8_MB = 4 * C8_BLK;
+constexpr int S_E8 = S_C8 + 4 * C8_MB;  // [4][128]  BACK8: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16 (L7..L0, TL,
+                                       //           T0..T15), then E1 once more as bytes for the DC sums (L7..L0 at 112, T0..T7 at 120)
 constexpr int S_F8 = S_E8 + 512;       // u32 [16]  flags between BACK and BACK8: b8Done (BACK8 -> BACK: Intra8x8 macroblocks of step n - 1 are in
                                        //           the tiles), woDone (BACK -> BACK8: the write-out of step n - 1 is through)
 constexpr int F8_DONE = 0, F8_WO = 4;
-constexpr int S_G8 = S_F8 + 64;        // T   [4][2 blk8][8][8]  FRONT: row-pass output of the two blocks of a pass (T: 4 bytes; 8 in the
-                                       //           WIDE build, whose teams are that much larger)
-constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 2048) : S_BYTES; }
+constexpr int S_G8 = S_F8 + 64;        // FRONT: row-pass output. 32-bit passes: T [4][2 blk8][8][8] (T: 4 bytes; 8 in the WIDE build, whose teams
+                                       //           are that much larger); packed form: i16 [4][4 blk8][8][8] with S_C8's strides, the four
+                                       //           column pairs of row r rotated by r >> 1 (rows written and columns read without conflicts)
+constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * C8_MB) : S_BYTES; }
 static_assert(S_CARRYM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
@@ -140,6 +156,9 @@ WV int ringy(int ts, int g, int e, int par) {
   return g == 0 ? ts + S_RINGY + 128 * par + 16 * (e & 7) : ts + S_RINGY + 256 + 64 * (g - 1) + 16 * (e & 3);
 }
 
+#ifndef DRYV_BAND_I8_PK16
+#define DRYV_BAND_I8_PK16 1   // (0: the 8x8 residuals always in 32 bits -- A/B builds)
+#endif
 #ifndef DRYV_BAND_TEAMS
 #define DRYV_BAND_TEAMS 4   // teams per workgroup (tools/band_variants.sh)
 #endif
@@ -322,11 +341,35 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
   if (hasI8) {
     for (int k = tid; k < 384; k += nthreads) wv::lds_st16(ldsBase + T_LS8 + 2 * k, P.ls8[k]);
     for (int k = tid; k < 576; k += nthreads) {
-      // index on the edge | which of E1 / F / G << 5 -> byte offset in BACK8's edge arrays (S_E8): the top samples sit 3 further
-      const int e = P.t8[k], idx = e & 31;
-      wv::lds_st8(ldsBase + T_T8 + k, (unsigned)((e & ~31) + (idx <= 8 ? idx : idx + 3)));
+      // index on the edge | which of E1 / F / G << 5 -> byte offset in BACK8's edge record (S_E8): a dword per sample
+      const int e = P.t8[k];
+      wv::lds_st8(ldsBase + T_T8 + k, (unsigned)(4 * (e & 31) + (e >> 5)));
     }
     for (int k = tid; k < 64; k += nthreads) wv::lds_st8(ldsBase + T_ZZ8 + P.zz8i[k], (unsigned)(2 * k));
+    for (int k = tid; k < 192; k += nthreads) {
+      const int m = k >> 5, p = (k >> 3) & 3, j = k & 7;
+      wv::lds_st32(ldsBase + T_LS8P + 4 * k, (unsigned)P.ls8[64 * m + 16 * p + j] | ((unsigned)P.ls8[64 * m + 16 * p + 8 + j] << 16));
+    }
+    for (int k = tid; k < 64; k += nthreads) {
+      const int r = k >> 3, j = k & 7;
+      wv::lds_st8(ldsBase + T_ZZ8P + P.zz8i[k], (unsigned)(32 * (r >> 1) + 4 * j + 2 * (r & 1)));
+    }
+    for (int qp = tid; qp < 52; qp += nthreads) {
+      // Exactness of the packed form. D = sum of |d| over the block's dequantised entries. Every value either 8-point pass
+      // forms is a sum of its inputs with weights of magnitude <= 1.5 (idct8: d1 -> e7, d7 -> e1) plus < 4 from the
+      // truncating shifts, so a row pass stays below 1.5 * (the row's share of D) + 4 and a column pass below
+      // 1.5 * sum over the rows of that + 4 + 32 <= 2.25 D + 84: D <= 14400 keeps everything inside int16. With S = the
+      // block's sum of |c| (>= any single |c|) and L = the largest LevelScale entry of qp % 6:
+      //   qp >= 36: |d| = |c| LS << (qp/6 - 6)                        -> D <= S L << shl
+      //   qp <  36: |d| <= (|c| LS + rnd) >> shr <= |c| LS / 2^shr + 1 -> D <= S L >> shr + 64 + 32 (rnd >> shr <= 1/2 per entry)
+      // and the product itself, which v_pk_mad_u16 forms modulo 2^16 before the shift: S L + 32 <= 32767.
+      const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
+      int L = 1;
+      for (int k = 0; k < 64; k++) L = max(L, (int)P.ls8[64 * qm + k]);
+      const int byProduct = 32700 / L;
+      const int byD = qd >= 6 ? 14400 / (L << (qd - 6)) : (int)min(((long long)(14400 - 96) << (6 - qd)) / L, 65535ll);
+      wv::lds_st16(ldsBase + T_THR8P + 2 * qp, (unsigned)min(min(byProduct, byD), 65535));
+    }
   }
 }
 
@@ -553,6 +596,14 @@ WV void residual_pass(const u32x4 c0, const u32x4 c1, int ldsBase, int qp, bool 
   inputsDone();
 }
 
+// lane i ^ 4 and i ^ 8 inside a 16-lane DPP row
+// (i ^ 4 = the quads of every eight lanes swapped = the eight mirrored, then every quad mirrored back: two DPP moves, the
+// second of which the compiler folds into the instruction that uses it; no select)
+WV int xor4(int v, bool) { return wv::dppx<DPP_QUAD(3, 2, 1, 0)>(wv::dppx<DPP_ROW_HALF_MIRROR>(v)); }
+WV int xor8(int v) { return wv::dppx<DPP_ROW_ROR(8)>(v); }
+WV int xor1(int v) { return wv::dppx<DPP_QUAD(1, 0, 3, 2)>(v); }
+WV int xor2(int v) { return wv::dppx<DPP_QUAD(2, 3, 0, 1)>(v); }
+
 // ---- 8x8 residuals of the step's Intra8x8 macroblocks (8.5.13, pred8x8.rs:51-150) ----------------------------------
 // 8-point butterfly shared by the row and the column pass (pred8x8.rs:85-141)
 template <typename T>
@@ -591,7 +642,7 @@ WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts,
     const int b8 = 2 * p + (i >> 3), r = i & 7;
     T dd[8], oo[8];
     if (mine) {
-      const u32x4 cr = wv::lds_u128(ts + S_C8 + 512 * g + 128 * b8 + 16 * r);
+      const u32x4 cr = wv::lds_u128(ts + S_C8 + C8_MB * g + C8_BLK * b8 + 16 * r);
       const u32x4 lr = wv::lds_u128(ldsBase + T_LS8 + 128 * qm + 16 * r);
       const unsigned cw[4] = {cr.x, cr.y, cr.z, cr.w}, lw[4] = {lr.x, lr.y, lr.z, lr.w};
 #pragma unroll
@@ -635,44 +686,115 @@ WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts,
   }
 }
 
+// 8-point butterfly on pairs (two rows, or two columns, per register)
+WV void idct8_pk(const unsigned d[8], unsigned o[8]) {
+  using namespace wv;
+  const unsigned e0 = pk_add(d[0], d[4]);
+  const unsigned e1 = pk_sub(pk_sub(pk_sub(d[5], d[3]), d[7]), pk_ashr1(d[7]));
+  const unsigned e2 = pk_sub(d[0], d[4]);
+  const unsigned e3 = pk_sub(pk_sub(pk_add(d[1], d[7]), d[3]), pk_ashr1(d[3]));
+  const unsigned e4 = pk_sub(pk_ashr1(d[2]), d[6]);
+  const unsigned e5 = pk_add(pk_add(pk_sub(d[7], d[1]), d[5]), pk_ashr1(d[5]));
+  const unsigned e6 = pk_add(d[2], pk_ashr1(d[6]));
+  const unsigned e7 = pk_add(pk_add(pk_add(d[3], d[5]), d[1]), pk_ashr1(d[1]));
+  const unsigned f0 = pk_add(e0, e6), f1 = pk_add(e1, pk_ashr2(e7)), f2 = pk_add(e2, e4), f3 = pk_add(e3, pk_ashr2(e5));
+  const unsigned f4 = pk_sub(e2, e4), f5 = pk_sub(pk_ashr2(e3), e5), f6 = pk_sub(e0, e6), f7 = pk_sub(e7, pk_ashr2(e1));
+  o[0] = pk_add(f0, f7);
+  o[1] = pk_add(f2, f5);
+  o[2] = pk_add(f4, f3);
+  o[3] = pk_add(f6, f1);
+  o[4] = pk_sub(f6, f1);
+  o[5] = pk_sub(f4, f3);
+  o[6] = pk_sub(f2, f5);
+  o[7] = pk_sub(f0, f7);
+}
+
+// The packed 16-bit form (exact under T_THR8P's bound, which the caller has checked for every Intra8x8 block of the step):
+// ONE pass over the macroblock's four blocks. Lane i of the macroblock: block i >> 2, rows 2p and 2p + 1 (p = i & 3) in
+// the halves of a register, then columns 2p and 2p + 1. In: the coefficients in S_C8, pair-interleaved (T_ZZ8P). Out: out[k] =
+// row k, columns 2p | 2p + 1 << 16 of block i >> 2.
+WV void residual8x8_pk16(bool mine, int lane, int qp, int ldsBase, int ts, unsigned out[8]) {
+  const int g = lane >> 4, i = lane & 15, p = i & 3;
+  const int blk = ts + S_C8 + C8_MB * g + C8_BLK * (i >> 2), g8 = ts + S_G8 + C8_MB * g + C8_BLK * (i >> 2);
+  // S_G8: (row r, column pair q) of the block at dword 4 r + ((q + (r >> 1)) & 3)
+  const int sw[4] = {4 * (p & 3), 4 * ((p + 1) & 3), 4 * ((p + 2) & 3), 4 * ((p + 3) & 3)};
+  if (mine) {
+    const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
+    const unsigned shl2 = (unsigned)max(qd - 6, 0) * 0x10001u, shr2 = (unsigned)max(6 - qd, 0) * 0x10001u;
+    const unsigned rnd2 = qd < 6 ? (0x10001u << (5 - qd)) : 0u;
+    unsigned dd[8], oo[8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const u32x4 r = wv::lds_u128(blk + 32 * p + 16 * h), l = wv::lds_u128(ldsBase + T_LS8P + 128 * qm + 32 * p + 16 * h);
+      const unsigned rw[4] = {r.x, r.y, r.z, r.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) dd[4 * h + j] = wv::pk_ashr(wv::pk_shl(wv::pk_mad(rw[j], lw[j], rnd2), shl2), shr2);   // (shl or shr is 0)
+    }
+    idct8_pk(dd, oo);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {   // rows 2p and 2p + 1 (both rotated by p), column j
+      wv::lds_st16(g8 + 32 * p + sw[j >> 1] + 2 * (j & 1), oo[j]);
+      wv::lds_st16(g8 + 32 * p + 16 + sw[j >> 1] + 2 * (j & 1), oo[j] >> 16);
+    }
+  }
+  wv::wave_sync();
+  if (mine) {
+    unsigned dd[8], oo[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) dd[k] = wv::lds_u32(g8 + 16 * k + sw[k >> 1]);   // row k, column pair p
+    dd[0] = wv::pk_add(dd[0], 0x00200020u);   // the rounding term of (x + 32) >> 6
+    idct8_pk(dd, oo);
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = wv::pk_ashr6(oo[k]);
+  }
+  wv::wave_sync();  // (S_C8 / S_G8 are reused by the next step)
+}
+
 // c0/c1: the 16 list entries this lane loaded: entries 16 * (i & 3) .. +15 of 8x8 block i >> 2. mine: this lane's macroblock
 // is a valid Intra8x8 one. Overflow handling as in residual_pass (thr8: |d| <= 2^23 keeps both 8-point passes in int32).
+// Returns whether the step took the packed form (wave-uniform): `out` is then in residual8x8_pk16's layout.
 template <bool WIDE>
-WV void residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp, int ldsBase, int ts, unsigned* status,
+WV bool residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp, int ldsBase, int ts, unsigned* status,
                     unsigned batchSeq, unsigned out[8]) {
   const int g = lane >> 4, i = lane & 15;
+  // the block's sum of |c| (four lanes hold a block's 64 entries) against the qp's bound of the packed form
+  bool pk = false;
+  if (DRYV_BAND_I8_PK16) {
+    unsigned sa = sum_abs16(c0, c1, false);
+    sa += (unsigned)xor1((int)sa);
+    sa += (unsigned)xor2((int)sa);
+    pk = !wv::any(mine && sa > wv::lds_u16(ldsBase + T_THR8P + 2 * qp));
+  }
   const int thr = (int)wv::lds_u16(ldsBase + T_THR8 + 2 * qp);
   bool big = false;
-  if (wv::any(mine && thr != 0xFFFF)) big = mine && thr != 0xFFFF && max_abs16(c0, c1, false) > thr;
-  // list order -> raster (frame/mod.rs:212-284): one 16-bit store per entry
+  if (!pk && wv::any(mine && thr != 0xFFFF)) big = mine && thr != 0xFFFF && max_abs16(c0, c1, false) > thr;
+  // list order -> raster (frame/mod.rs:212-284) resp. the packed form's pair-interleaved block: one 16-bit store per entry
   if (mine) {
-    const int dst = ts + S_C8 + 512 * g + 128 * (i >> 2);
-    const u32x4 zp = wv::lds_u128(ldsBase + T_ZZ8 + 16 * (i & 3));
+    const int dst = ts + S_C8 + C8_MB * g + C8_BLK * (i >> 2);
+    const u32x4 zp = wv::lds_u128(ldsBase + (pk ? T_ZZ8P : T_ZZ8) + 16 * (i & 3));
     const unsigned zw[4] = {zp.x, zp.y, zp.z, zp.w}, cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
     for (int k = 0; k < 16; k++)
       wv::lds_st16(dst + (int)((zw[k >> 2] >> (8 * (k & 3))) & 0xffu), (k & 1) ? cw[k >> 1] >> 16 : cw[k >> 1]);
   }
   wv::wave_sync();
+  if (pk) {
+    residual8x8_pk16(mine, lane, qp, ldsBase, ts, out);
+    return true;
+  }
   if (WIDE) {
     if (wv::any(big)) {
       residual8x8_passes<long long>(mine, g, i, qp, ldsBase, ts, out);
-      return;
+      return false;
     }
   } else if (big) {
     wv::atomic_or(status, 2u);
     wv::atomic_max(status + 4, ~batchSeq);
   }
   residual8x8_passes<int>(mine, g, i, qp, ldsBase, ts, out);
+  return false;
 }
 
-// lane i ^ 4 and i ^ 8 inside a 16-lane DPP row
-// (i ^ 4 = the quads of every eight lanes swapped = the eight mirrored, then every quad mirrored back: two DPP moves, the
-// second of which the compiler folds into the instruction that uses it; no select)
-WV int xor4(int v, bool) { return wv::dppx<DPP_QUAD(3, 2, 1, 0)>(wv::dppx<DPP_ROW_HALF_MIRROR>(v)); }
-WV int xor8(int v) { return wv::dppx<DPP_ROW_ROR(8)>(v); }
-WV int xor1(int v) { return wv::dppx<DPP_QUAD(1, 0, 3, 2)>(v); }
-WV int xor2(int v) { return wv::dppx<DPP_QUAD(2, 3, 0, 1)>(v); }
 
 // One reconstructed row of 4 pixels: prediction as two u16 pairs, residual as two i16 pairs
 WV unsigned recon_row(unsigned p01, unsigned p23, unsigned r01, unsigned r23) {
@@ -1075,6 +1197,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       PH(1);  // record decode
       // ================= residuals ================================================================================
       unsigned rA[8];
+      bool pk8 = false;   // (wave-uniform) the step's Intra8x8 residuals come in the packed form's layout
       EXP_REP(0)
       if (EXP_SKIP(0)) {
 #pragma unroll
@@ -1120,7 +1243,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         // Intra8x8 macroblocks: their lanes' rA becomes 16 residuals of one column per 8x8 block pass (residual8x8)
         if (HAS_I8 && wv::any(valid && kind == 1)) {
           unsigned r8[8];
-          residual8x8<WIDE>(cC0, cC1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, A.batchSeq, r8);
+          pk8 = residual8x8<WIDE>(cC0, cC1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, A.batchSeq, r8);
 #pragma unroll
           for (int k = 0; k < 8; k++) rA[k] = kind == 1 ? r8[k] : rA[k];
         }
@@ -1170,13 +1293,22 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         // this lane holds column j = i & 7 of 8x8 blocks i >> 3 (rA[0..3]) and 2 + (i >> 3) (rA[4..7]), rows 2m, 2m+1 per
         // word: element (row k, column j) goes to 4x4 block (bx, by) = (2 * (b8 & 1) + (j >> 2), 2 * (b8 >> 1) + (k >> 2)),
         // position (k & 3, j & 3)
-        const int j = i & 7;
-        const int dst = ts + S_RES + RES_BUF * buf + RES_ROW * g + 64 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
+        if (pk8) {
+          // the packed form: rA[k] = row k, columns 2q | 2q + 1 of 8x8 block b8 = i >> 2 (q = i & 3): one dword of 4x4 block
+          // (2 * (b8 & 1) + (q >> 1), 2 * (b8 >> 1) + (k >> 2))
+          const int b8 = i >> 2, q = i & 3;
+          const int dst = ts + S_RES + RES_BUF * buf + RES_ROW * g + 32 * (8 * (b8 >> 1) + 2 * (b8 & 1) + (q >> 1)) + 4 * (q & 1);
 #pragma unroll
-        for (int pk = 0; pk < 16; pk++) {
-          const int p = pk >> 3, k = pk & 7;
-          const unsigned w = rA[4 * p + (k >> 1)];
-          wv::lds_st16(dst + 256 * p + 128 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
+          for (int k = 0; k < 8; k++) wv::lds_st32(dst + 128 * (k >> 2) + 8 * (k & 3), rA[k]);
+        } else {
+          const int j = i & 7;
+          const int dst = ts + S_RES + RES_BUF * buf + RES_ROW * g + 64 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
+#pragma unroll
+          for (int pk = 0; pk < 16; pk++) {
+            const int p = pk >> 3, k = pk & 7;
+            const unsigned w = rA[4 * p + (k >> 1)];
+            wv::lds_st16(dst + 256 * p + 128 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
+          }
         }
       } else {
         const int dst = ts + S_RES + RES_BUF * buf + hResOff;
@@ -1706,18 +1838,16 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
           const int elHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(e1Lo), e1Hi);
           int erHi = wv::dpp<DPP_ROW_SHL(1)>(e1Hi, e1Hi);
           if (i >= 8) erHi = e1Hi;
-          // three byte arrays, 32 bytes apart: E1, F, G at position k (k <= 8) / k + 3 (the top samples: T0 dword-aligned)
-          const int kLo = e8 + (i <= 8 ? i : i + 3);
-          wv::lds_st8(kLo, (unsigned)e1Lo);
-          wv::lds_st8(kLo + 32, (unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2);
-          wv::lds_st8(kLo + 64, (unsigned)(e1Lo + erLo + 1) >> 1);
+          // one dword per edge sample k: E1 | F << 8 | G << 16 (a table entry is the byte's offset: 4 k + which); E1 once
+          // more as bytes for the DC sums (L7..L0 at 112, T0..T7 at 120: two aligned dwords each)
+          wv::lds_st32(e8 + 4 * i, (unsigned)e1Lo | (((unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2) << 8) | (((unsigned)(e1Lo + erLo + 1) >> 1) << 16));
+          if (i != 8) wv::lds_st8(e8 + 112 + (i < 8 ? i : i - 1), (unsigned)e1Lo);
           if (i <= 8) {
-            wv::lds_st8(e8 + i + 19, (unsigned)e1Hi);
-            wv::lds_st8(e8 + i + 19 + 32, (unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2);
-            wv::lds_st8(e8 + i + 19 + 64, (unsigned)(e1Hi + erHi + 1) >> 1);
+            wv::lds_st32(e8 + 4 * (i + 16), (unsigned)e1Hi | (((unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2) << 8) | (((unsigned)(e1Hi + erHi + 1) >> 1) << 16));
+            if (i == 0) wv::lds_st8(e8 + 127, (unsigned)e1Hi);   // (T7 is sample 16)
           }
           wv::wave_sync();
-          // four pixels of row py: x0 .. x0 + 3; a table entry is the sample's byte offset in those arrays
+          // four pixels of row py: x0 .. x0 + 3
           const unsigned te4 = te4s[b8];
           unsigned pr[4];
 #pragma unroll
@@ -1727,8 +1857,8 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
             const int req = (int)((0x217771021ull >> (4 * mode)) & 7ull);
             if ((req & ~have) != 0) pr[0] = pr[1] = pr[2] = pr[3] = 0;   // quirk Q4
             if (mode == 2) {  // DC (pred8x8.rs:350-394)
-              const int sumL = (int)wv::sad4(wv::lds_u32(e8)) + (int)wv::sad4(wv::lds_u32(e8 + 4));
-              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 12)) + (int)wv::sad4(wv::lds_u32(e8 + 16));
+              const int sumL = (int)wv::sad4(wv::lds_u32(e8 + 112)) + (int)wv::sad4(wv::lds_u32(e8 + 116));
+              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 120)) + (int)wv::sad4(wv::lds_u32(e8 + 124));
               const int dc = (topAv && leftAv) ? (sumT + sumL + 8) >> 4 : leftAv ? (sumL + 4) >> 3 : topAv ? (sumT + 4) >> 3 : 128;
               pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
             }

@@ -9,7 +9,7 @@
 
 namespace dryv {
 
-// Band kernel (band_kernel.h): a team of three waves per 4-row band; grid = workgroups of band_teams_per_block() teams.
+// Band kernel (band_kernel.h): a team of three waves (four with the 8x8 transform) per 4-row band; grid = workgroups of band_teams_per_block() teams.
 size_t band_lds_bytes(bool hasI8, bool wide, int teams);
 int band_teams_per_block(bool hasI8, bool wide);
 int band_blocks_per_cu(bool hasI8, bool wide);

@@ -6,9 +6,10 @@
 
 namespace dryv {
 
-// A workgroup = TEAMS_PER_WG teams of a FRONT, a BACK and a CHROMA wave. The fast build for streams without the 8x8
-// transform uses all 80 VGPRs that six waves per SIMD allow (lane-constant work hoisted up to that limit); the one with it is compiled for 5 waves per SIMD (96 VGPRs), the wide builds (64-bit residual
-// arithmetic, re-run of a flagged batch only) for 4.
+// A workgroup = TEAMS_PER_WG teams of a FRONT, a BACK and a CHROMA wave (and a BACK8 wave in the builds for streams with the
+// 8x8 transform). The fast build for streams without the 8x8 transform uses all 80 VGPRs that six waves per SIMD allow
+// (lane-constant work hoisted up to that limit); the one with it is compiled for 5 waves per SIMD (96 VGPRs: five
+// four-wave teams per CU), the wide builds (64-bit residual arithmetic, re-run of a flagged batch only) for 4.
 // Grid shape: tools/band_variants.sh (measurements in DESIGN.md).
 #ifndef DRYV_BAND_WPS
 #define DRYV_BAND_WPS 6   // waves per SIMD the fast build is compiled for (<= 80 VGPRs)
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(64 * ((HAS_I8 || WIDE) ? 4 : band::WAVES_PER_W
   }
   __syncthreads();  // the only workgroup-level synchronisation: the teams are independent from here on
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // consecutive waves of a workgroup go to different SIMDs: a team's three waves never share one
+  // consecutive waves of a workgroup go to different SIMDs: a team's three (four) waves never share one
   const int team = wave / WPT, role = wave - team * WPT;
   const int ts = ldsBase + tEnd + team * band::team_bytes(HAS_I8, WIDE);
   // Wave priority by role (s_setprio: the SIMD's arbiter prefers the higher one when several waves can issue). FRONT is a
@@ -70,9 +71,10 @@ size_t band_lds_bytes(bool hasI8, bool wide, int teams) { return (size_t)(hasI8 
 // Workgroup geometry per build (tools/ab_inproc.py with -DDRYV_BAND_TEAMS / -DDRYV_BAND_WGS_PER_CU variants):
 //   * fast build, no 8x8 transform (80 VGPRs): 4 teams x 2 workgroups per CU; 1 x 8 measures the same, 2 x 4, 3 x 2 and
 //     1 x 7 are 3 ... 13 % slower.
-//   * fast build with the 8x8 transform (96 VGPRs, 5 waves per SIMD; more LDS per team): ONE team per workgroup, five per
-//     CU. Three-team workgroups left only one of them resident on a CU: 4.21 ms for the 100 x 4K batch against 3.59
-//     (2 teams) and 3.05 (1 team, 5 or 6 workgroups per CU).
+//   * fast build with the 8x8 transform (96 VGPRs, 5 waves per SIMD; more LDS per team): ONE four-wave team per workgroup,
+//     five per CU = all 20 wave slots. Three-team workgroups left only one of them resident on a CU: 4.21 ms for the
+//     100 x 4K batch against 3.59 (2 teams) and 3.05 (1 team, 5 or 6 workgroups per CU); with the fourth wave 2.68;
+//     four workgroups per CU 3.00, six (80 VGPRs, 14 spilled) 2.72.
 //   * wide builds (re-run of a flagged batch only; up to 128 VGPRs): one team per workgroup, four per CU.
 int band_teams_per_block(bool hasI8, bool wide) { return (hasI8 || wide) ? 1 : band::TEAMS_PER_WG; }
 int band_blocks_per_cu(bool hasI8, bool wide) { return wide ? 4 : hasI8 ? DRYV_BAND_WGS_PER_CU_I8 : DRYV_BAND_WGS_PER_CU; }

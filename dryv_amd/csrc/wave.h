@@ -84,6 +84,11 @@ WV unsigned pk_add(unsigned a, unsigned b) {
 WV unsigned pk_ashr5(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 5)); }
 WV unsigned pk_ashr1(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 1)); }
 WV unsigned pk_ashr6(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 6)); }
+WV unsigned pk_ashr2(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 2)); }
+// per-half shift left by the low four bits of the matching half of sh (v_pk_lshlrev_b16)
+WV unsigned pk_shl(unsigned a, unsigned sh) {
+  return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) << (__builtin_bit_cast(s16x2, sh) & (s16x2)15)));
+}
 // per-half arithmetic shift right by the low four bits of the matching half of sh (v_pk_ashrrev_i16)
 WV unsigned pk_ashr(unsigned a, unsigned sh) {
   return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> (__builtin_bit_cast(s16x2, sh) & (s16x2)15)));

@@ -153,6 +153,10 @@ WV unsigned pk_ashr(unsigned a, unsigned sh) {
 }
 WV unsigned pk_ashr1(unsigned a) { return pk_ashr(a, 0x00010001u); }
 WV unsigned pk_ashr6(unsigned a) { return pk_ashr(a, 0x00060006u); }
+WV unsigned pk_ashr2(unsigned a) { return pk_ashr(a, 0x00020002u); }
+WV unsigned pk_shl(unsigned a, unsigned sh) {
+  return (((a & 0xffff) << (sh & 15)) & 0xffff) | ((((a >> 16) << ((sh >> 16) & 15)) & 0xffff) << 16);
+}
 WV unsigned pk_sub(unsigned a, unsigned b) { return ((a - b) & 0xffff) | (((a >> 16) - (b >> 16)) << 16); }
 WV unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
   return (((a & 0xffff) * (b & 0xffff) + (c & 0xffff)) & 0xffff) | ((((a >> 16) * (b >> 16) + (c >> 16)) & 0xffff) << 16);

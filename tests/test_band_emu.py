@@ -15,7 +15,7 @@ import pytest
 
 import oracle
 from dryv_amd import abi, synth
-from util import first_mismatch, packed16_bound_batches
+from util import first_mismatch, packed16_bound_batches, packed16_8x8_bound_batches
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import emu  # noqa: E402
@@ -156,6 +156,14 @@ def test_emulated_fast_path_at_its_exactness_bound():
                                                                         else rng.choice([-1, 1], size=384))
                     co[a] = sign * lim
                 check(fp, 1, mbs, co.astype(np.int16))
+
+
+def test_emulated_packed16_8x8_path_at_its_bound():
+    """The 8x8 residuals run on packed 16-bit pairs when every Intra8x8 block of a step has sum |c| within the per-qp bound
+    (T_THR8P); one unit more sends the step through the 32-bit passes. Both must equal the oracle bit for bit."""
+    fp = abi.make_frame_params(5, 4, transform_8x8=True)
+    for qp, bump, mbs, co in packed16_8x8_bound_batches(fp, synth):
+        check(fp, 1, mbs, co)
 
 
 def test_emulated_packed16_path_at_its_bound():
