@@ -13,7 +13,7 @@ import pytest
 
 import oracle
 from dryv_amd import abi, synth, Frame, ReconError
-from util import first_mismatch, make_coeffs, make_mb, split_planes, packed16_bound_batches
+from util import first_mismatch, make_coeffs, make_mb, split_planes, packed16_bound_batches, packed16_8x8_bound_batches
 
 pytestmark = pytest.mark.gpu
 
@@ -583,4 +583,13 @@ def test_packed16_residual_path_at_its_bound(recon_ctx):
     above (the step then takes the 32-bit path). Bit-exact against the oracle's 64-bit arithmetic either way."""
     fp = abi.make_frame_params(9, 6)
     for qp, bump, mbs, co in packed16_bound_batches(fp, synth, frames=2):
+        assert_parity(recon_ctx, fp, 2, mbs, co)
+
+
+@pytest.mark.gpu
+def test_packed16_8x8_residual_path_at_its_bound(recon_ctx):
+    """The packed 16-bit form of the 8x8 residual: every 8x8 block's sum |c| at the per-qp bound that admits it (T_THR8P),
+    and one above (the step then takes the 32-bit passes). Bit-exact against the oracle's 64-bit arithmetic either way."""
+    fp = abi.make_frame_params(9, 6, transform_8x8=True)
+    for qp, bump, mbs, co in packed16_8x8_bound_batches(fp, synth, frames=2):
         assert_parity(recon_ctx, fp, 2, mbs, co)
