@@ -23,10 +23,6 @@ struct KParams {
   // 64-bit path. thr4: 4x4 blocks (8.5.12), thr8: 8x8 blocks (8.5.13).
   uint16_t thr4[52];
   uint16_t thr8[52];
-  // row kernel (int32 throughout): largest |coefficient| of a macroblock of this QPY for which every path it may take
-  // (4x4 / 8x8 blocks, Intra16x16 DC, chroma DC and AC at both chroma QPs) stays exact; beyond it the batch is re-run on
-  // the band kernel's wide build
-  uint16_t thr_row[52];
   int transform8x8;   // frame parameter transform_8x8_mode_flag: whether mb_kind 1 may occur
 };
 

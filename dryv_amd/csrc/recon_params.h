@@ -135,23 +135,6 @@ inline int build_params(const dryv_frame_params* fp, uint32_t n_frames, KParams*
     P->thr4[qp] = (uint16_t)(t4 >= 32768 ? 0xFFFF : t4);
     P->thr8[qp] = (uint16_t)(t8 >= 32768 ? 0xFFFF : t8);
   }
-  // row kernel: one conservative bound per QPY (see KParams::thr_row)
-  for (int qp = 0; qp < 52; qp++) {
-    long long t = P->thr4[qp];
-    if (P->transform8x8) t = std::min<long long>(t, P->thr8[qp]);
-    {  // Intra16x16 DC (pred16x16.rs:465-479): |f| <= 16 max|c|, |f * LS(0,0)| << max(qp/6 - 6, 0) kept below 2^26
-      const int qd = qp / 6, qm = qp % 6;
-      t = std::min<long long>(t, (1ll << 22) / ((long long)P->ls4[qm * 16] << (qd > 6 ? qd - 6 : 0)));
-    }
-    for (int pl = 0; pl < 2; pl++) {  // chroma at QP'c (8.5.8): AC like a 4x4 block; DC: |f| <= 4 max|c|, (f * LS(0,0)) << (qpc/6) below 2^30
-      const int qpi = std::min(std::max(qp + (pl ? P->cqo_cr : P->cqo_cb), 0), 51);
-      static const int QPC[22] = {29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
-      const int qpc = qpi < 30 ? qpi : QPC[qpi - 30];
-      t = std::min<long long>(t, P->thr4[qpc]);
-      t = std::min<long long>(t, (1ll << 28) / ((long long)P->ls4[(qpc % 6) * 16] << (qpc / 6)));
-    }
-    P->thr_row[qp] = (uint16_t)(t >= 32768 ? 0xFFFF : t);
-  }
   return DRYV_OK;
 }
 
