@@ -146,7 +146,10 @@ constexpr int F8_DONE = 0, F8_WO = 4;
 constexpr int S_G8 = S_F8 + 64;        // FRONT: row-pass output. 32-bit passes: T [4][2 blk8][8][8] (T: 4 bytes; 8 in the WIDE build, whose teams
                                        //           are that much larger); packed form: i16 [4][4 blk8][8][8] with S_C8's strides, the four
                                        //           column pairs of row r rotated by r >> 1 (rows written and columns read without conflicts)
-constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * C8_MB) : S_BYTES; }
+// builds without it append instead:
+constexpr int S_MREC = S_BYTES;        // [64][32]  CHROMA: the mode records of a pre-pass iteration, on their way to memory as whole lines (the 8x8
+                                       //           builds have no room for it: 5 x 31.4 KB per CU; theirs leave lane by lane)
+constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * C8_MB) : S_BYTES + 2048; }
 static_assert(S_CARRYM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
@@ -1033,13 +1036,29 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
         if (!isI4) w0 = w1 = w2 = w3 = w4 = dcMask = 0u;
       }
       if (HAS_I8 && is8) w0 = ((unsigned)M[0] << 3) | ((unsigned)M[2] << 11) | ((unsigned)M[8] << 19) | ((unsigned)M[10] << 27);
-      if (valid) {
-        unsigned* rec = recF + (size_t)MREC_WORDS * mb;
-        wv::st_g128_sc1(rec, u32x4{w0, w1, w2, w3});
-        wv::st_g128_sc1(rec + 4, u32x4{w4, word0, dcMask, bottom});
+      if (HAS_I8) {
+        if (valid) {
+          unsigned* rec = recF + (size_t)MREC_WORDS * mb;
+          wv::st_g128_sc1(rec, u32x4{w0, w1, w2, w3});
+          wv::st_g128_sc1(rec + 4, u32x4{w4, word0, dcMask, bottom});
+        }
+      } else {
+        // The 64 records of the iteration are 2 KB of contiguous memory: through LDS, so that each of the two store
+        // instructions writes whole lines -- lane by lane (16 of every 32 bytes per instruction) every write-through store
+        // reaches memory as a partial line of its own: 1.4 M write requests more per 300 pictures, and 3 % of the launch
+        const int stg = ts + S_MREC;
+        unsigned* rec0 = recF + (size_t)MREC_WORDS * (unsigned)((G.r0 + g) * W + x0);   // the batch's first record
+        wv::lds_st128(stg + 32 * lane, u32x4{w0, w1, w2, w3});
+        wv::lds_st128(stg + 32 * lane + 16, u32x4{w4, word0, dcMask, bottom});
+        wv::wave_sync();
+        // lane l: 16-byte chunks l and 64 + l of the batch (chunk c = half c & 1 of its record c >> 1)
+        const u32x4 va = wv::lds_u128(stg + 16 * lane), vb = wv::lds_u128(stg + 1024 + 16 * lane);
+        unsigned* const dst = rec0 + 4 * lane;
+        if (x0 + (lane >> 1) < W) wv::st_g128_sc1(dst, va);
+        if (x0 + 32 + (lane >> 1) < W) wv::st_g128_sc1(dst + 256, vb);
       }
     }
-    if (g == nR - 1) wv::wave_sync();  // (lane 63's right columns: the next batch's macroblock A)
+    wv::wave_sync();  // (the records' staging area; lane 63's right columns: the next batch's macroblock A)
   }
   // the records are complete once the last store has been written through
   wv::wait_vm(0);
