@@ -159,6 +159,14 @@ WV int ringy(int ts, int g, int e, int par) {
   return g == 0 ? ts + S_RINGY + 128 * par + 16 * (e & 7) : ts + S_RINGY + 256 + 64 * (g - 1) + 16 * (e & 3);
 }
 
+// A band's last row publishes its progress (bottom lines visible up to macroblock n) every so many steps -- each publication
+// is a write-through store plus the wait for the line stores before it. Every second step for the builds without the 8x8
+// transform (300 x 1080p: 1.263 / 1.205 / 1.224 / 1.289 ms for 1 / 2 / 4 / 8: 576 k fewer small write requests are worth
+// more than the follower's half step); every step with it (100 x 4K, thirteen bands of a picture following each other:
+// 2.658 / 2.701 / 2.741 / 2.865 ms)
+#ifndef DRYV_BAND_PUBLISH_EVERY
+#define DRYV_BAND_PUBLISH_EVERY(hasI8) ((hasI8) ? 1 : 2)
+#endif
 #ifndef DRYV_BAND_I8_PK16
 #define DRYV_BAND_I8_PK16 1   // (0: the 8x8 residuals always in 32 bits -- A/B builds)
 #endif
@@ -1499,7 +1507,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       // ---- hand-off traffic. Publish: the previous step ended with the write-through stores of its last-row
       // macroblock's bottom chroma lines (and the staged row segments); once vmcnt says that everything this wave has
       // issued is done the macroblock is published.
-      if (linePend) {
+      if (linePend && (s & (DRYV_BAND_PUBLISH_EVERY(HAS_I8) - 1)) == 0) {
         wv::wait_vm(0);
         const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
         if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
@@ -2053,7 +2061,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 
       // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom line (and the
       // staged row segments). Once vmcnt says that everything this wave has issued is done the macroblock is published.
-      if (linePend) {
+      if (linePend && (s & (DRYV_BAND_PUBLISH_EVERY(HAS_I8) - 1)) == 0) {
         wv::wait_vm(0);
         const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
         if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
