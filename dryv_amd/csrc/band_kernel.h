@@ -159,14 +159,6 @@ WV int ringy(int ts, int g, int e, int par) {
   return g == 0 ? ts + S_RINGY + 128 * par + 16 * (e & 7) : ts + S_RINGY + 256 + 64 * (g - 1) + 16 * (e & 3);
 }
 
-// A band's last row publishes its progress (bottom lines visible up to macroblock n) every so many steps -- each publication
-// is a write-through store plus the wait for the line stores before it. Every second step for the builds without the 8x8
-// transform (300 x 1080p: 1.263 / 1.205 / 1.224 / 1.289 ms for 1 / 2 / 4 / 8: 576 k fewer small write requests are worth
-// more than the follower's half step); every step with it (100 x 4K, thirteen bands of a picture following each other:
-// 2.658 / 2.701 / 2.741 / 2.865 ms)
-#ifndef DRYV_BAND_PUBLISH_EVERY
-#define DRYV_BAND_PUBLISH_EVERY(hasI8) ((hasI8) ? 1 : 2)
-#endif
 #ifndef DRYV_BAND_I8_PK16
 #define DRYV_BAND_I8_PK16 1   // (0: the 8x8 residuals always in 32 bits -- A/B builds)
 #endif
@@ -272,8 +264,9 @@ struct Args {
   uint8_t* yuv;
   unsigned* status;     // [0] bit 0 unsupported record, bit 1 a block beyond the fast build's arithmetic, bit 2 a band gave up waiting;
                         // [1..3] where it gave up; [4] ~(sequence number of the first queued batch that raised bit 1)
-  unsigned* progY;      // [frame][band]: macroblocks of the band's last row whose bottom luma line is visible
-  unsigned* progC;      // [frame][band]: the same for its bottom chroma lines
+  unsigned* handoff;    // [frame][band that has a band below][mb][16]: the bottom lines of the band's last row, in four 16-byte
+                        // granules {8 pixels, tag, 0}: luma 0..7, luma 8..15, Cb, Cr. tag = gen: a granule is there when its tag is
+  unsigned gen;         // the launch's generation (never 0, never repeated over the life of the workspace)
   unsigned* progM;      // [frame][band]: W once the band's mode records (below) are visible
   unsigned* rowModes;   // [mb][8]: the mode record of every macroblock (MREC_*), written by the band's mode pre-pass
   unsigned* taskCounter;
@@ -858,6 +851,31 @@ WV void team_wait_ge(int addr, unsigned want) {
   while ((int)((unsigned)wv::rfl((int)wv::lds_u32(addr)) - want) < 0) wv::sleep_team();
 }
 
+constexpr int HAND_WORDS = 16;   // dwords per macroblock of the hand-off records (Args::handoff)
+// The hand-off record of a macroblock of the band above, eight lanes (li = 0..7) reading one dword each of the two
+// granules at dword offset `off` of the record (luma: 0, chroma: 8): dwords 0, 1 / 4, 5 the pixels, 2 / 6 the tags. `v`: what
+// the lanes requested a step ago (or just now). Polls -- all eight lanes again, a granule is written whole -- until both tags
+// are there (bounded: see SPIN_LIMIT).
+WV unsigned await_granules(const unsigned* rec, unsigned v, bool fetchLane, int li, unsigned tag, unsigned* status, unsigned task, int s,
+                           int lane) {
+  unsigned spins = 0;
+  while (wv::any(fetchLane && (li & 3) == 2 && v != tag)) {
+    wv::sleep_short();
+    if (fetchLane) v = wv::ld_sc1(rec);
+    if (++spins > SPIN_LIMIT) {
+      // every spin is bounded: a band above that never gets there is reported (status bit 2 + where), not waited for
+      if (lane == 0) {
+        wv::atomic_or(status, 4u);
+        status[1] = task;
+        status[2] = ((unsigned)s << 16) | 0xffffu;
+        status[3] = v;
+      }
+      break;
+    }
+  }
+  return v;
+}
+
 // Polls progress words of the band above until they reach `need` (bounded: see SPIN_LIMIT). Lanes 0..31 read pa,
 // lanes 32..63 pb (the same word twice where a wave follows only one).
 WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned known, unsigned need, unsigned W, unsigned* status,
@@ -1142,7 +1160,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
     const unsigned* const recF = A.rowModes + mbFrame * MREC_WORDS;   // the frame's mode records
-    const unsigned* const upProgY = A.progY + (size_t)G.f * nBands + G.b - 1;
+    // the band above's hand-off records (bands that have a band below: nBands - 1 per frame)
+    const unsigned* const handUp = A.handoff + ((size_t)G.f * (nBands - 1) + (G.b - 1)) * (size_t)W * HAND_WORDS;
     const int claimStep = max(nSteps - DRYV_BAND_CLAIM_AHEAD, 0);
 
     // the band's prediction modes, all of them, are derived before its first step (CHROMA: band_modes)
@@ -1188,11 +1207,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     load_coefs_luma(0, kN1);
 
     PH(0);  // claim, prologue loads
-    unsigned upKnown = 0;    // what this wave knows of the band above's progress (luma lines)
-    unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
-    bool flagPend = false;
-    unsigned lineN = 0;      // the band above's words of macroblock s+1, requested during the previous step (haveN)
-    bool haveN = false;
+    unsigned lineN = 0;      // this lane's dword of the band above's hand-off record of macroblock s+1, requested during the previous step
 
     for (int s = 0; s < nSteps; s++, gstep++) {
       TRACE(1, s + 1);
@@ -1281,35 +1296,18 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       }
       PH(2);  // luma residuals
       // ---- hand-off traffic, placed here so that nothing in front of the residuals waits for it.
-      // lanes 0..3: bottom luma line of macroblock s+1 of the band above's last row; lanes 16..19: of macroblock 0 at step
-      // 0. When the band above is far enough ahead, macroblock s+2 is requested as well and kept in a register until
-      // the next step: the request then has a whole step to come back (haveN / lineN).
+      // lanes 0..7: the two luma granules of macroblock s+1 of the band above's last row (a dword each); lanes 16..23: of
+      // macroblock 0 at step 0. A granule carries its own tag: no progress word, no ordering between the band above's stores.
+      // Macroblock s+2 is requested now and looked at in the next step: the request has a whole step to come back.
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
-      const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-      auto fetch_up = [&](int mb) -> unsigned {
-        return wv::ld_sc1((const unsigned*)(planeY + (unsigned)((16 * r0 - 1) * pitchY + 16 * mb + 4 * li)));
-      };
-      bool haveNext = false;
+      const bool fetchLane = needUp && li < 8 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
       if (needUp && !EXP_SKIP(2)) {
-        // the band above must have finished macroblock s+1 (BACK's neighbour C) before its line is fetched. Its progress
-        // word is read one step ahead (flagV), so this normally costs nothing; otherwise poll.
-        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
-        flagPend = false;
-        upKnown = poll_progress(upProgY, upProgY, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
-        wv::compiler_fence();
-        if (fetchLane) {
-          if (haveN && lane < 16) lineV = lineN;
-          else lineV = fetch_up(mbx);
-        }
-        haveNext = s + 2 < W && upKnown >= (unsigned)(s + 3);
-        if (haveNext && lane < 16 && li < 4) lineN = fetch_up(s + 2);
-        if (upKnown < (unsigned)W) {
-          flagV = wv::ld_sc1(upProgY);
-          flagPend = true;
-        }
+        const unsigned* const rec = handUp + (HAND_WORDS * mbx + li);
+        if (fetchLane) lineV = (s > 0 && lane < 16) ? lineN : wv::ld_sc1(rec);
+        lineV = await_granules(rec, lineV, fetchLane, li, A.gen, A.status, task, s, lane);
+        if (lane < 8 && s + 2 < W) lineN = wv::ld_sc1(rec + HAND_WORDS);
       }
-      haveN = haveNext;
       if (HAS_I8 || EXP_SKIP(0) || EXP_DUP_IS(0)) load_coefs_luma(s + 1, kN1);  // (otherwise: requested inside the residual pass)
       PH(3);  // hand-off traffic, coefficient prefetch
 
@@ -1350,7 +1348,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         wv::lds_st32(ts + S_INFO + 32 * buf + 28, 0u);  // rounds of the block chain that have a DC block: below
       }
       // what was fetched from the band above goes into row 0's luma ring (BACK's)
-      if (fetchLane) wv::lds_st32(ringy(ts, 0, mbx, (int)(seq & 1u)) + 4 * li, lineV);
+      if (fetchLane && (li & 2) == 0) wv::lds_st32(ringy(ts, 0, mbx, (int)(seq & 1u)) + 4 * ((li & 1) | ((li >> 2) << 1)), lineV);
       wv::wave_sync();
       // the step's modes from the band's pre-pass (band_modes): words 0..5 of the macroblock's mode record are the table
       // rows of BACK's block chain (S_MSEQ), word 6 the chain rounds that have a DC block -- BACK skips the DC arithmetic
@@ -1400,15 +1398,13 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
   const int aLeftRd = wv::opaque(ts + S_STC + 16 * CW * hg + 8 * CW * (hi >> 3) + CW * (hi & 7) + 7);  // + 8 * slot: column 7
   const int aLeftWr = wv::opaque(ts + S_LEFTC + 16 * hg + 8 * (hi >> 3) + (hi & 7));
   // write-through of the band's bottom lines: + 8 * r0 * pitchC + 8 * s   (8 * x = 8 * s - 16 * g)
-  const unsigned oBot = (unsigned)wv::opaque((int)((hi < 2 ? offCb : offCr) + (unsigned)((8 * hg + 7) * pitchC - 16 * hg + 4 * (hi & 1))));
   // flush with 64 lanes per macroblock row (NSC = 8): lane = (plane, pixel row, 16-byte segment)
   constexpr int FLR = 8 * NSC;
   const int fw = lane0 % FLR, fpl = fw / (FLR / 2), ffy = (fw / (NSC / 2)) & 7, fseg = fw % (NSC / 2);
   const int aFlush = wv::opaque(ts + S_STC + 8 * CW * fpl + CW * ffy + 16 * fseg);                      // + 16 * CW * row
   const unsigned oFlush = (unsigned)wv::opaque((int)((fpl ? offCr : offCb) + (unsigned)(ffy * pitchC + 16 * fseg)));  // + 8 * (r0 + row) * pitchC + 8 * xp
-  const int fseg2 = wv::opaque(2 * fseg + (ffy == 7 ? 64 : 0));   // 2 * segment; bit 6: pixel row 7
+  const int fseg2 = wv::opaque(2 * fseg);   // 2 * segment
   // the band above's bottom lines (lanes 0..1 of a row group Cb, 2..3 Cr): + (8 * r0 - 1) * pitchC + 8 * macroblock
-  const unsigned oUp = (unsigned)wv::opaque((int)(((hi & 15) < 2 ? offCb : offCr) + (unsigned)(4 * (hi & 1))));
 
   for (unsigned seq = 0;; seq++) {
     team_wait_ge(ts + S_FLAGS + F_HEAD, seq + 1);
@@ -1423,8 +1419,9 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     const size_t mbFrame = (size_t)G.f * (size_t)(W * H);
     const uint8_t* const mbsF = (const uint8_t*)(A.mbs + mbFrame);
     const uint8_t* const coefF = (const uint8_t*)(A.coeffs + mbFrame * 384);
-    unsigned* const myProg = A.progC + (size_t)G.f * nBands + G.b;
-    const unsigned* const upProg = myProg - 1;
+    // hand-off records: this band's (if it has a band below) and the band above's
+    unsigned* const handMy = A.handoff + ((size_t)G.f * (nBands - 1) + G.b) * (size_t)W * HAND_WORDS;
+    const unsigned* const handUp = handMy - (size_t)W * HAND_WORDS;
     unsigned* const recF = A.rowModes + mbFrame * MREC_WORDS;   // the frame's mode records
 
     // ---- the band's prediction modes, all of them, before its first step: FRONT hands a task over well before the luma
@@ -1471,12 +1468,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     for (int k = 0; k < 8; k++) rB[k] = 0;
     load_coefs_chroma(0);
     PH(0);  // task, prologue loads
-    unsigned upKnown = 0;    // what this wave knows of the band above's chroma progress
-    unsigned flagV = 0;      // the band above's progress word, fetched during the previous step
-    bool flagPend = false;
-    bool linePend = false;   // bottom lines of the band's last row were stored in the previous step, not yet published
-    unsigned lineN = 0;      // the band above's line words of macroblock s+1, requested during the previous step
-    bool haveN = false;
+    unsigned lineN = 0;      // this lane's dword of the band above's hand-off record of macroblock s+1, requested during the previous step
 
     for (int s = 0; s < nSteps; s++) {
       const bool evenStep = (s & 1) == 0;
@@ -1504,41 +1496,17 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       // dC: the residual lane's macroblock (of its step of the pair); dEven / dOdd: the prediction lane's (of this step)
       const int kindR = (int)(dC & 0xffu), qpR = (int)(dC >> 24);
 
-      // ---- hand-off traffic. Publish: the previous step ended with the write-through stores of its last-row
-      // macroblock's bottom chroma lines (and the staged row segments); once vmcnt says that everything this wave has
-      // issued is done the macroblock is published.
-      if (linePend && (s & (DRYV_BAND_PUBLISH_EVERY(HAS_I8) - 1)) == 0) {
-        wv::wait_vm(0);
-        const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
-        if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
-        linePend = false;
-      }
-      // lanes 0..3: bottom lines of macroblock s+1 of the band above (0..1 Cb, 2..3 Cr); lanes 16..19: macroblock 0 at
-      // step 0; macroblock s+2 is requested a step early when the band above is far enough ahead (as in FRONT)
+      // ---- hand-off traffic. lanes 0..7: the two chroma granules (Cb, Cr) of macroblock s+1 of the band above (a dword
+      // each); lanes 16..23: of macroblock 0 at step 0; macroblock s+2 is requested a step early (as in FRONT)
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
-      const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
-      auto fetch_up = [&](int mb) -> unsigned {
-        return wv::ld_sc1((const unsigned*)(planeY + (oUp + (unsigned)((8 * r0 - 1) * pitchC + 8 * mb))));
-      };
-      bool haveNext = false;
+      const bool fetchLane = needUp && li < 8 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
       if (needUp && !EXP_SKIP(9)) {
-        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
-        flagPend = false;
-        upKnown = poll_progress(upProg, upProg, upKnown, (unsigned)min(s + 2, W), (unsigned)W, A.status, task, s, lane);
-        wv::compiler_fence();
-        if (fetchLane) {
-          if (haveN && lane < 16) lineV = lineN;
-          else lineV = fetch_up(mbx);
-        }
-        haveNext = s + 2 < W && upKnown >= (unsigned)(s + 3);
-        if (haveNext && lane < 16 && li < 4) lineN = fetch_up(s + 2);
-        if (upKnown < (unsigned)W) {
-          flagV = wv::ld_sc1(upProg);
-          flagPend = true;
-        }
+        const unsigned* const rec = handUp + (HAND_WORDS * mbx + 8 + li);
+        if (fetchLane) lineV = (s > 0 && lane < 16) ? lineN : wv::ld_sc1(rec);
+        lineV = await_granules(rec, lineV, fetchLane, li, A.gen, A.status, task, s, lane);
+        if (lane < 8 && s + 2 < W) lineN = wv::ld_sc1(rec + HAND_WORDS);
       }
-      haveN = haveNext;
       PH(1);  // hand-off traffic
 
       // ================= chroma residuals ==========================================================================
@@ -1583,7 +1551,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         load_coefs_chroma(s + 2);
         kN1 = load_kind(s + 2);
       }
-      if (fetchLane) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * li, lineV);
+      if (fetchLane && (li & 2) == 0) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * ((li & 1) | ((li >> 2) << 1)), lineV);
       wv::wave_sync();
       PH(2);  // chroma residuals, prefetch
 
@@ -1697,9 +1665,11 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         unsigned v = 0;
         if (i < 4) v = wv::lds_u32(aBot + 8 * slot);
         if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(aRing + RINGC_ENT * (x & 3), v);
-        if (hasBelow && wv::any(valid && g == gl)) {  // the band's last row: written through for the band below
-          if (valid && g == gl && i < 4) wv::st_sc1((unsigned*)(planeY + (oBot + (unsigned)(8 * r0 * pitchC + 8 * s))), v);
-          linePend = true;
+        if (hasBelow && wv::any(valid && g == gl)) {
+          // the band's last row: a granule per plane {8 pixels, tag, 0} into the hand-off record, written through (lanes 0 / 2
+          // of the row: Cb / Cr, whose first dword v is; the second is the next lane's)
+          const unsigned v1 = (unsigned)wv::dppx<DPP_ROW_SHL(1)>((int)v);
+          if (valid && g == gl && (i == 0 || i == 2)) wv::st_g128_sc1(handMy + (HAND_WORDS * x + 8 + 2 * i), u32x4{v, v1, A.gen, 0u});
         }
       }
       // left neighbour copy: chroma column 7
@@ -1709,7 +1679,6 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       }
       wv::wave_sync();
       // flush the staged rows: every NSC-th macroblock, or at the end of a row: 8 * NSC contiguous bytes per pixel row.
-      // The bottom lines of a band that has a band below were already written through.
       EXP_REP(8)
       if (!EXP_SKIP(8) && wv::any(valid && (slot == NSC - 1 || x == W - 1))) {
         constexpr int LR = 8 * NSC;  // lanes per macroblock row: 2 planes x 8 pixel rows x NSC / 2 segments of 16 bytes
@@ -1725,7 +1694,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
           if (LR == 64) {
             // (everything lane-dependent was prepared before the task loop; the row's part is wave-uniform)
             const int room = fx - xp;   // macroblocks of the segment in front of fx
-            const bool ok = (fseg2 & 63) <= room && !(hasBelow && fg == gl && (fseg2 & 64));
+            const bool ok = (fseg2 & 63) <= room;
             const u32x4 v = wv::lds_u128(aFlush + 16 * CW * fg);
             uint8_t* dst = planeY + (oFlush + (unsigned)(8 * (r0 + fg) * pitchC + 8 * xp));
             if (ok) {
@@ -1735,7 +1704,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
             continue;
           }
           const int pl = w / (LR / 2), fy = (w / (NSC / 2)) & 7, seg = w % (NSC / 2);
-          const bool ok = rowFlush && xp + 2 * seg <= fx && !(hasBelow && fg == gl && fy == 7);
+          const bool ok = rowFlush && xp + 2 * seg <= fx;
           const u32x4 v = wv::lds_u128(ts + S_STC + 16 * CW * fg + 8 * CW * pl + CW * fy + 16 * seg);
           uint8_t* dst = planeY + ((pl ? offCr : offCb) + (unsigned)((8 * (r0 + fg) + fy) * pitchC + 8 * xp + 16 * seg));
           if (ok) {
@@ -1746,11 +1715,6 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       }
       wv::wave_sync();
       PH(4);  // chroma lines, copies, flush
-    }
-    // the band's chroma is complete once its last stores have been written through
-    if (hasBelow) {
-      wv::wait_vm(0);
-      if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
     }
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
@@ -1924,8 +1888,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
   // per-task state (set at step 0 of each task)
   BandGeo G = band_geo(0u, nF, W, H);
   uint8_t* planeY = A.yuv;
-  unsigned* myProg = A.progY;
-  bool linePend = false;
+  unsigned* handMy = A.handoff;   // the band's hand-off records (if it has a band below)
   int par = 0;  // task parity (row 0's luma ring)
 
   for (unsigned gstep = 0;; gstep++) {
@@ -1939,8 +1902,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       par = wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 24));
       TLINE(task, 1, TNOW());
       planeY = A.yuv + (size_t)G.f * frameBytes;
-      myProg = A.progY + (size_t)G.f * nBands + G.b;
-      linePend = false;
+      handMy = A.handoff + ((size_t)G.f * (nBands - 1) + G.b) * (size_t)W * HAND_WORDS;
     }
     const int r0 = G.r0, nR = G.nR, gl = G.gl;
     const bool hasBelow = G.hasBelow;
@@ -2059,14 +2021,6 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       wv::wave_sync();
       PH(2);  // Intra16x16
 
-      // Publish: the previous step ended with the write-through store of its last-row macroblock's bottom line (and the
-      // staged row segments). Once vmcnt says that everything this wave has issued is done the macroblock is published.
-      if (linePend && (s & (DRYV_BAND_PUBLISH_EVERY(HAS_I8) - 1)) == 0) {
-        wv::wait_vm(0);
-        const int done = min(max(s - 2 * gl, 0), W);  // row gl finished macroblock s-1-2*gl
-        if (lane == 0) wv::st_sc1(myProg, (unsigned)done);
-        linePend = false;
-      }
       PH(3);  // top-right copy, publish
       const bool anyI4 = !EXP_SKIP(4) && wv::any(valid && kind == 0);
 
@@ -2202,8 +2156,11 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         if (i < 4) v = wv::lds_u32(tile + TILE_STRIDE * 16 + 8 + 16 * slot + 4 * i);
         if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ringy(ts, g + 1, x, par) + 4 * i, v);
         if (hasBelow && wv::any(valid && g == gl)) {
-          if (valid && g == gl && i < 4) wv::st_sc1((unsigned*)(planeY + (unsigned)((16 * r + 15) * pitchY + 16 * x + 4 * i)), v);
-          linePend = true;
+          // the band's last row: two granules {8 pixels, tag, 0} into the hand-off record, written through (lanes 0 / 2 of the
+          // row, whose dword v is the granule's first; the second is the next lane's). The tag travels with the pixels: the
+          // band below needs no progress word, and this wave no wait for its stores.
+          const unsigned v1 = (unsigned)wv::dppx<DPP_ROW_SHL(1)>((int)v);
+          if (valid && g == gl && (i == 0 || i == 2)) wv::st_g128_sc1(handMy + (HAND_WORDS * x + 2 * i), u32x4{v, v1, A.gen, 0u});
         }
       }
       // left neighbour copy: luma column 15 (also the tile's x = -1 border when the next macroblock is slot 0)
@@ -2214,7 +2171,6 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       }
       wv::wave_sync();
       // flush the staged rows: every NSY-th macroblock, or at the end of a row: 16 * NSY contiguous bytes per pixel row.
-      // The bottom line of a band that has a band below was already written through.
       EXP_REP(5)
       if (!EXP_SKIP(5) && wv::any(valid && ((x & (NSY - 1)) == NSY - 1 || x == W - 1))) {
         constexpr int LR = 16 * NSY;  // lanes per macroblock row: 16 pixel rows x NSY segments of 16 bytes
@@ -2227,7 +2183,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           const bool rowFlush = fg < nR && fx >= 0 && fx < W && ((fx & (NSY - 1)) == NSY - 1 || fx == W - 1);
           if (LR >= 64 && !rowFlush) continue;
           const int fy = (w / NSY) & 15, seg = w % NSY;
-          const bool ok = rowFlush && xp + seg <= fx && !(hasBelow && fg == gl && fy == 15);
+          const bool ok = rowFlush && xp + seg <= fx;
           const int src = ts + S_TILE + TILE_BYTES * (NP * fg + (seg >> 1)) + TILE_STRIDE * (fy + 1) + 8 + 16 * (seg & 1);
           const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
           if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + seg)), u32x4{lo.x, lo.y, hi.x, hi.y});
@@ -2236,11 +2192,6 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       wv::wave_sync();
       if (HAS_I8 && lane == 0) wv::lds_st32(ts + S_F8 + F8_WO, gstep + 1);  // BACK8 may start the next step
       PH(5);  // line, copies, flush
-      // the band's luma is complete once its last stores have been written through
-      if (s == G.nSteps - 1 && hasBelow) {
-        wv::wait_vm(0);
-        if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
-      }
       if (s == G.nSteps - 1) TLINE(task, 2, TNOW());
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)

@@ -15,8 +15,11 @@ int band_teams_per_block(bool hasI8, bool wide);
 int band_blocks_per_cu(bool hasI8, bool wide);
 size_t band_workspace_bytes(const KParams& P);
 size_t band_reset_bytes(const KParams& P);      // leading bytes of the workspace a launch needs zeroed
+size_t band_handoff_offset(const KParams& P);   // the hand-off records between bands: tagged with the launch's generation, zeroed
+size_t band_handoff_bytes(const KParams& P);    //   once per workspace layout (never per launch)
 size_t band_profile_offset(const KParams& P);   // diagnostic builds: per-wave phase sums / breadcrumbs behind the workspace
+// gen: the launch's generation: not 0, and different from that of every earlier launch on this workspace layout
 hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                       void* d_workspace, int grid, bool wide, unsigned batch_seq, hipStream_t stream);
+                       void* d_workspace, int grid, bool wide, unsigned batch_seq, unsigned gen, hipStream_t stream);
 
 }  // namespace dryv

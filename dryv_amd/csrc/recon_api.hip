@@ -50,6 +50,11 @@ struct dryv_recon_ctx {
   // kernel workspace (task counter, per-row progress, bottom-row modes): grow-only
   void* d_work = nullptr;
   size_t cap_work = 0;
+  // the hand-off records between bands carry the launch's generation as their tag: they are zeroed when the workspace is
+  // (re)allocated or laid out for other picture dimensions / batch sizes, never per launch
+  unsigned launch_gen = 0;
+  const void* hand_ws = nullptr;   // the workspace and the layout the records were last zeroed for
+  int hand_W = 0, hand_H = 0, hand_frames = 0;
   int num_cus = 256;
   int grid_override = 0;
   bool force_wide = false;  // DRYV_RECON_FORCE_WIDE (test hook): every launch with the WIDE build (64-bit residual arithmetic)
@@ -86,6 +91,7 @@ int fail(dryv_recon_ctx* ctx, hipError_t e, const char* what) {
 int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
   if (*cap >= need) return DRYV_OK;
   if (*p) (void)hipFree(*p);
+  if (p == &ctx->d_work) ctx->hand_ws = nullptr;   // (a new workspace: its hand-off records are not zeroed yet)
   *p = nullptr;
   *cap = 0;
   hipError_t e = hipMalloc(p, need);
@@ -105,6 +111,29 @@ size_t workspace_bytes(const KParams& P) {
   return b;
 }
 
+// The per-launch part of the workspace (task counter, progress words) zeroed on the stream; the hand-off records zeroed if
+// this is another workspace or another layout than the last launch's. Returns the launch's generation in *gen.
+int prepare_workspace(dryv_recon_ctx* ctx, const KParams& P, unsigned* gen) {
+  hipError_t e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+  unsigned g = ctx->launch_gen + 1;
+  const bool other = ctx->hand_ws != ctx->d_work || ctx->hand_W != P.W || ctx->hand_H != P.H || ctx->hand_frames != P.n_frames;
+  if (other || g == 0) {
+    if (dryv::band_handoff_bytes(P) != 0) {
+      e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_handoff_offset(P), 0, dryv::band_handoff_bytes(P), ctx->stream);
+      if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(hand-off records)");
+    }
+    ctx->hand_ws = ctx->d_work;
+    ctx->hand_W = P.W;
+    ctx->hand_H = P.H;
+    ctx->hand_frames = P.n_frames;
+    if (g == 0) g = 1;
+  }
+  ctx->launch_gen = g;
+  *gen = g;
+  return DRYV_OK;
+}
+
 // the event pair the next timed launch records
 void next_events(dryv_recon_ctx* ctx) {
   const unsigned k = ctx->ev_n++ % dryv_recon_ctx::kEvRing;
@@ -119,8 +148,8 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, wide);
   if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
   if (grid < 1) grid = 1;
-  e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+  unsigned gen = 0;
+  if (int st = prepare_workspace(ctx, P, &gen)) return st;
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE) || defined(DRYV_BAND_TIMELINE)
   e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_profile_offset(P), 0, (size_t)65536 * 16 * 8 + (size_t)65536 * 32 * 2, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(profile)");
@@ -128,7 +157,7 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   next_events(ctx);
   e = hipEventRecord(ctx->ev_start, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, (unsigned)ctx->queued.size(), ctx->stream);
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, (unsigned)ctx->queued.size(), gen, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "band_kernel launch");
   e = hipEventRecord(ctx->ev_stop, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
@@ -148,8 +177,9 @@ int launch_chunk(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const
   const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, false);
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, false);
   grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
-  if ((e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream)) != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
-  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, 0u, ctx->stream);
+  unsigned gen = 0;
+  if (int st = prepare_workspace(ctx, P, &gen)) return st;
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, 0u, gen, ctx->stream);
   return e == hipSuccess ? DRYV_OK : fail(ctx, e, "band_kernel launch");
 }
 

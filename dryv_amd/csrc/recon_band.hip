@@ -79,19 +79,23 @@ size_t band_lds_bytes(bool hasI8, bool wide, int teams) { return (size_t)(hasI8 
 int band_teams_per_block(bool hasI8, bool wide) { return (hasI8 || wide) ? 1 : band::TEAMS_PER_WG; }
 int band_blocks_per_cu(bool hasI8, bool wide) { return wide ? 4 : hasI8 ? DRYV_BAND_WGS_PER_CU_I8 : DRYV_BAND_WGS_PER_CU; }
 
-// Workspace: [task counter | pad to 256][luma | chroma | modes progress words | pad to 256][mode records, 32 bytes per macroblock]
-// [diagnostics]
+// Workspace: [task counter | pad to 256][modes progress words | pad to 256][mode records, 32 bytes per macroblock]
+// [hand-off records, 64 bytes per macroblock of every band's last row][diagnostics]
 static size_t band_prog_words(const KParams& P) { return (size_t)P.n_frames * ((P.H + 3) / 4); }
-static size_t band_prog_bytes(const KParams& P) { return (3 * band_prog_words(P) * 4 + 255) & ~(size_t)255; }
+static size_t band_prog_bytes(const KParams& P) { return (band_prog_words(P) * 4 + 255) & ~(size_t)255; }
 size_t band_reset_bytes(const KParams& P) { return 256 + band_prog_bytes(P); }
-size_t band_profile_offset(const KParams& P) {
+size_t band_handoff_offset(const KParams& P) {
   return (256 + band_prog_bytes(P) + (size_t)P.n_frames * P.W * P.H * (4 * band::MREC_WORDS) + 255) & ~(size_t)255;
 }
+size_t band_handoff_bytes(const KParams& P) {
+  return ((size_t)P.n_frames * ((P.H + 3) / 4 - 1) * P.W * (4 * band::HAND_WORDS) + 255) & ~(size_t)255;
+}
+size_t band_profile_offset(const KParams& P) { return band_handoff_offset(P) + band_handoff_bytes(P); }
 size_t band_workspace_bytes(const KParams& P) { return band_profile_offset(P); }
 
 // wide: the build whose residual passes fall back to 64-bit arithmetic (see band_kernel.h, residual_pass).
 hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                       void* d_workspace, int grid, bool wide, unsigned batch_seq, hipStream_t stream) {
+                       void* d_workspace, int grid, bool wide, unsigned batch_seq, unsigned gen, hipStream_t stream) {
   unsigned char* wsb = (unsigned char*)d_workspace;
   band::Args A;
   A.mbs = (const dryv_mb_desc*)d_mbs;
@@ -99,9 +103,9 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   A.yuv = (uint8_t*)d_yuv;
   A.status = d_status;
   A.taskCounter = (unsigned*)wsb;
-  A.progY = (unsigned*)(wsb + 256);
-  A.progC = A.progY + band_prog_words(P);
-  A.progM = A.progC + band_prog_words(P);
+  A.progM = (unsigned*)(wsb + 256);
+  A.handoff = (unsigned*)(wsb + band_handoff_offset(P));
+  A.gen = gen;
   A.rowModes = (unsigned*)(wsb + 256 + band_prog_bytes(P));
   A.profile = nullptr;
   A.waveBase = 0;

@@ -132,7 +132,9 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
   const int WPT = dryv::band::waves_per_team(g_P.transform8x8 != 0);
   const int n_waves = WPT * n_teams;
   const int nBands = (g_P.H + 3) / 4;
-  std::vector<unsigned> prog((size_t)3 * n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H * dryv::band::MREC_WORDS, 0xEEEEEEEEu);
+  std::vector<unsigned> prog((size_t)n_frames * nBands, 0u), modes((size_t)n_frames * g_P.W * g_P.H * dryv::band::MREC_WORDS, 0xEEEEEEEEu);
+  // the hand-off records: zeroed once, like the host API's; each pass is a launch with a generation of its own
+  std::vector<unsigned> hand((size_t)n_frames * (nBands > 1 ? nBands - 1 : 0) * g_P.W * dryv::band::HAND_WORDS + 1, 0u);
   // like the host API: the fast build first; if it flags a block beyond int32 (status bit 1), the batch again with the wide build
   unsigned status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int pass = 0; pass < 2; pass++) {
@@ -140,7 +142,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
     memset(status, 0, sizeof status);
     std::fill(prog.begin(), prog.end(), 0u);
     g_wide = pass == 1;
-    g_A = dryv::band::Args{mbs, coeffs, yuv, status, prog.data(), prog.data() + (size_t)n_frames * nBands, prog.data() + (size_t)2 * n_frames * nBands, modes.data(), &counter, nullptr, 0, 0u};
+    g_A = dryv::band::Args{mbs, coeffs, yuv, status, hand.data(), (unsigned)(pass + 1), prog.data(), modes.data(), &counter, nullptr, 0, 0u};
     wv::g_body = body;
     std::vector<std::unique_ptr<wv::Wave>> waves;
     const int teamBytes = dryv::band::team_bytes(g_P.transform8x8 != 0, true);   // (one size for both passes: the wide build's)
@@ -169,6 +171,7 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
       auto progress = [&]() {  // anything a waiting wave could be waiting for: progress words, the teams' flag words
         unsigned long long t = 0;
         for (unsigned v : prog) t += v;
+        for (unsigned v : hand) t += v;   // (the tags of the hand-off records)
         for (auto& L : teamLds)
           for (int q = 0; q < 64; q += 4) {
             unsigned v;
