@@ -674,7 +674,7 @@ int dryv_recon_debug_band_timeline(dryv_recon_ctx* ctx, int n_tasks, unsigned lo
 }
 #endif
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE)
-/* diagnostic build only: reads n_waves x 8 trace words and `n_prog` progress words while the kernel may still be running
+/* diagnostic build only: reads n_waves x 8 trace words and `n_prog` (mode-record) progress words while the kernel may still be running
    (own stream) */
 int dryv_recon_debug_band_trace(dryv_recon_ctx* ctx, int n_waves, unsigned* out, int n_prog, unsigned* prog_out) {
   if (!ctx || !out || n_waves > 65536 || !ctx->d_work) return DRYV_E_INVALID;
@@ -682,7 +682,7 @@ int dryv_recon_debug_band_trace(dryv_recon_ctx* ctx, int n_waves, unsigned* out,
   if (!s2 && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return DRYV_E_DEVICE;
   hipError_t e = hipMemcpyAsync(out, (unsigned char*)ctx->d_work + dryv::band_profile_offset(ctx->last_P) + (size_t)65536 * 16 * 8,
                                 (size_t)n_waves * 32, hipMemcpyDeviceToHost, s2);
-  if (e == hipSuccess && n_prog > 0) e = hipMemcpyAsync(prog_out, (unsigned char*)ctx->d_work + 256, (size_t)n_prog * 4, hipMemcpyDeviceToHost, s2);  /* luma words, then chroma words */
+  if (e == hipSuccess && n_prog > 0) e = hipMemcpyAsync(prog_out, (unsigned char*)ctx->d_work + 256, (size_t)n_prog * 4, hipMemcpyDeviceToHost, s2);  /* the bands' mode-record words */
   if (e == hipSuccess) e = hipStreamSynchronize(s2);
   return e == hipSuccess ? DRYV_OK : DRYV_E_DEVICE;
 }
