@@ -179,10 +179,10 @@ constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 #define DRYV_BAND_PRIO_BACK 2
 #endif
 #ifndef DRYV_BAND_PRIO_CHROMA
-#define DRYV_BAND_PRIO_CHROMA 2
+#define DRYV_BAND_PRIO_CHROMA 1
 #endif
 #ifndef DRYV_BAND_PRIO_FRONT
-#define DRYV_BAND_PRIO_FRONT 0
+#define DRYV_BAND_PRIO_FRONT 1
 #endif
 #ifndef DRYV_BAND_PRIO_FRONT_I8   // (builds with the 8x8 transform, where FRONT carries the 8x8 residuals as well: measured 0 = 1
 #define DRYV_BAND_PRIO_FRONT_I8 DRYV_BAND_PRIO_FRONT   //  < 2 (+2.8 %) < 3 (+18 %) on the 4K batch)

@@ -45,12 +45,11 @@ __global__ void __launch_bounds__(64 * ((HAS_I8 || WIDE) ? 4 : band::WAVES_PER_W
   // consecutive waves of a workgroup go to different SIMDs: a team's three (four) waves never share one
   const int team = wave / WPT, role = wave - team * WPT;
   const int ts = ldsBase + tEnd + team * band::team_bytes(HAS_I8, WIDE);
-  // Wave priority by role (s_setprio: the SIMD's arbiter prefers the higher one when several waves can issue). FRONT is a
-  // producer that runs up to two steps ahead of the other two; BACK is the wave on a band's critical path, and CHROMA's
-  // bottom lines are what the band below's CHROMA waits for: the two consumers go first. Measured on the 300-picture
-  // batch (tools/band_variants.sh, same box within a line): no priorities 1.444 ms / BACK 2: 1.388 / BACK 3: 1.397;
-  // BACK 2: 1.433 / BACK 2 + CHROMA 1: 1.373 / BACK = CHROMA = 2: 1.336-1.370 / 1, 1: 1.335-1.371 / 3, 2: 1.335-1.370;
-  // FRONT raised with them, or alone: 1.47-1.49 (no gain or worse).
+  // Wave priority by role (s_setprio: the SIMD's arbiter prefers the higher one when several waves can issue). BACK is the
+  // wave on a band's critical path: one above the other two. Measured on the 300-picture batch, in one process against the
+  // shipped 2 / 1 / 1 (BACK / CHROMA / FRONT): 2 / 2 / 0 (rounds 2 and 3 until the hand-off records) +1.0 ... +1.8 %, 3 / 2 / 2
+  // equal, 3 / 1 / 1 and 3 / 2 / 1 +1 %, 2 / 2 / 2 +4 %, FRONT above CHROMA (2 / 1 / 2, 3 / 1 / 2) +6 ... +7 %, 1 / 0 / 0 +1.3 %;
+  // round 2, before the mode pre-pass and the hand-off changes: no priorities 1.444 ms / BACK 2 alone 1.388 / 2 / 2 / 0 1.336-1.370.
   if (role == 1 && DRYV_BAND_PRIO_BACK) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK);
   if (HAS_I8 && role == 3 && DRYV_BAND_PRIO_BACK8) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_BACK8);
   if (role == 2 && DRYV_BAND_PRIO_CHROMA) __builtin_amdgcn_s_setprio(DRYV_BAND_PRIO_CHROMA);
