@@ -184,10 +184,12 @@ constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 #ifndef DRYV_BAND_PRIO_FRONT
 #define DRYV_BAND_PRIO_FRONT 1
 #endif
-#ifndef DRYV_BAND_PRIO_FRONT_I8   // (builds with the 8x8 transform, where FRONT carries the 8x8 residuals as well: measured 0 = 1
-#define DRYV_BAND_PRIO_FRONT_I8 DRYV_BAND_PRIO_FRONT   //  < 2 (+2.8 %) < 3 (+18 %) on the 4K batch)
+// (builds with the 8x8 transform, 4K batch, against the shipped 2 / 2 / 1 / 1 (BACK / BACK8 / CHROMA / FRONT) = 2.563 ms: FRONT 0
+// +3.0 %, CHROMA 2 +3.7 %, BACK8 1 +0.5 %, 3 / 2 / 1 / 1 and 3 / 3 / 2 / 2 equal; with CHROMA at 2: FRONT 2 +2.8 %, 3 +18 %)
+#ifndef DRYV_BAND_PRIO_FRONT_I8
+#define DRYV_BAND_PRIO_FRONT_I8 DRYV_BAND_PRIO_FRONT
 #endif
-#ifndef DRYV_BAND_PRIO_BACK8      // (0: +2.6 %)
+#ifndef DRYV_BAND_PRIO_BACK8
 #define DRYV_BAND_PRIO_BACK8 DRYV_BAND_PRIO_BACK
 #endif
 #ifndef DRYV_BAND_PRIO_MODES
