@@ -222,6 +222,20 @@ def test_device_resident_path(recon_ctx):
     assert np.array_equal(d_o.cpu().numpy(), want)
 
 
+def test_handoff_records_across_launches_and_layouts(recon_ctx):
+    """Bands hand their bottom lines over in tagged records of the workspace (tag = the launch's generation; the records are
+    zeroed per workspace layout, never per launch). One context, launches alternating between geometries whose workspaces
+    overlap differently (the records of one sit where the mode records or the records of another were), the same batch
+    twice in a row (every tag of the previous launch is still there, one generation old), pictures of a single band (no
+    hand-off at all) in between: every picture bit-exact."""
+    seq = [(13, 9, 3, False), (5, 21, 2, True), (13, 9, 3, False), (13, 9, 3, False), (40, 4, 1, False), (7, 17, 1, True),
+           (13, 9, 2, False), (5, 21, 2, True), (64, 5, 2, False), (13, 9, 3, False)]
+    for k, (W, H, frames, t8) in enumerate(seq):
+        fp = abi.make_frame_params(W, H, transform_8x8=t8)
+        mbs, co = synth.generate(fp, synth.config(i4x4=0.5, i8x8=0.3 if t8 else 0.0), 4200 + (k % 4), 0, frames)
+        assert_parity(recon_ctx, fp, frames, mbs, co)
+
+
 def test_queued_device_submits(recon_ctx):
     """dryv_recon_submit_device_queued: several batches behind each other on the stream, one sync (what bench.py times).
     Three different batches of different sizes into buffers of their own; then a queue in which the middle batch has
