@@ -933,7 +933,8 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
                    unsigned* recF, const unsigned* upProgM, unsigned* myProgM) {
   const int lane = wv::lane_id();
   const int W = P.W;
-  if (G.hasAbove) poll_progress(upProgM, upProgM, 0u, (unsigned)W, (unsigned)W, A.status, task, -1, lane);
+  unsigned upKnownM = 0;   // macroblocks of the band above's last row whose records are known to be there
+  const bool perBatch = W > 128;
   if (lane < 4) wv::lds_st32(ts + S_CARRYM + 4 * lane, 0x02020202u);
   wv::wave_sync();
   // One iteration = 64 macroblocks of one row: batch after batch, the band's rows inside a batch (row g's neighbour B
@@ -952,6 +953,12 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
 #pragma clang loop unroll(disable)
   for (int it = 0; it < nIter; it++) {
     const int xb = it / nR, g = it - xb * nR, x0 = 64 * xb;
+    // Batch by batch: the band above publishes its last row's records after every batch, and this band needs those of a
+    // batch only when it gets there -- the pre-passes of a picture's bands overlap instead of queueing up behind each other
+    // (pictures of three batches or more; narrower ones publish once: 120 macroblocks wide, the second publication and its
+    // drain cost 1 % and overlap nothing; 240 wide, four batches: -1.7 %)
+    if (G.hasAbove && g == 0)
+      upKnownM = poll_progress(upProgM, upProgM, upKnownM, (unsigned)(perBatch ? min(x0 + 64, W) : W), (unsigned)W, A.status, task, -1, lane);
     const int x = x0 + lane;
     const bool valid = x < W;
     const bool xIs0 = x == 0, xLast = x + 1 >= W;
@@ -1089,10 +1096,14 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
       }
     }
     wv::wave_sync();  // (the records' staging area; lane 63's right columns: the next batch's macroblock A)
+    // a batch's records of the band's last row are complete once their stores have been written through (the last batch's
+    // count is W: FRONT of this band's team waits for the LDS flag, the band below for this word)
+    if (G.hasBelow && g == nR - 1 && (perBatch || it == nIter - 1)) {
+      wv::wait_vm(0);
+      if (lane == 0) wv::st_sc1(myProgM, (unsigned)min(x0 + 64, W));
+    }
   }
-  // the records are complete once the last store has been written through
   wv::wait_vm(0);
-  if (G.hasBelow && lane == 0) wv::st_sc1(myProgM, (unsigned)W);
 }
 
 // ==================================================================================================================
