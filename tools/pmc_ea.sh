@@ -3,7 +3,7 @@ OUT=$R/gpurun_out/ea; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for so in $R/dryv_amd/lib/var/*.so; do
   n=$(basename $so .so)
-  DRYV_RECON_LIB=$so timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 $R/bench.py --steps 3 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-verify > $OUT/pmc_$n.log 2>&1 || echo "pmc $n failed"
+  DRYV_RECON_LIB=$so timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 $R/bench.py --workload ${WL:-C2_1080p_intra_4x4} --steps 3 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-verify > $OUT/pmc_$n.log 2>&1 || echo "pmc $n failed"
 done
 cd $R
 python3 - <<'PY'
