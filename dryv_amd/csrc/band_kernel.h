@@ -1207,7 +1207,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       const int l = lane0;
       const int i = l & 15;
       const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);
-      const int kind = (int)(d0 & 0xffu);
+      const int kind = (int)(d0 & 3u);
       const unsigned mo = mb_index(step, l >> 4) * 768u;
       // Intra16x16: [DC 16][blk x AC 15]; the lane takes the 16 entries that END with its block's 15 AC, so list
       // position k (1..15) is AC k-1 (pred16x16.rs:33-46) and entry 0 is replaced by the DC term
@@ -1245,7 +1245,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       unsigned lineV = 0;
 
       // ---- record decode (lane-per-block luma organisation: row g) ------------------------------------------
-      const int kind = (int)(kCur & 0xffu), i16mode = (int)((kCur >> 8) & 0xffu), qp = (int)(kCur >> 24);
+      const int kind = (int)(kCur & 3u), i16mode = (int)((kCur >> 8) & 3u), qp = (int)(kCur >> 24);
       // the mode record of step s+1, the first record word of step s+2: requested now, a whole step (two) before they are
       // needed
       kN2 = load_kind(s + 2);
@@ -1509,7 +1509,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       const bool needUp = hasAbove && s < W;
       unsigned lineV = 0;
       // dC: the residual lane's macroblock (of its step of the pair); dEven / dOdd: the prediction lane's (of this step)
-      const int kindR = (int)(dC & 0xffu), qpR = (int)(dC >> 24);
+      const int kindR = (int)(dC & 3u), qpR = (int)(dC >> 24);
 
       // ---- hand-off traffic. lanes 0..7: the two chroma granules (Cb, Cr) of macroblock s+1 of the band above (a dword
       // each); lanes 16..23: of macroblock 0 at step 0; macroblock s+2 is requested a step early (as in FRONT)
@@ -1574,7 +1574,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       EXP_REP(7)
       if (!EXP_SKIP(7)) {
         const unsigned dP = evenStep ? dEven : dOdd;
-        const int kindC = (int)(dP & 0xffu), cmode = (int)((dP >> 16) & 0xffu);
+        const int kindC = (int)(dP & 3u), cmode = (int)((dP >> 16) & 3u);
         const int ringP = ts + S_RINGC + RINGC_ROW * gc + 8 * cpl;
         const int leftC = ts + S_LEFTC + 16 * gc + 8 * cpl;
         const unsigned tw = wv::lds_u32(ringP + RINGC_ENT * (xC & 3) + 4 * ccx);
