@@ -1785,7 +1785,7 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
     const bool mbA = x > 0;
     const int slot = x & 1;
     const int tile = tile_of(ts, g, x);
-    const int kind = (int)(wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g) & 0xffu);
+    const int kind = (int)(wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g) & 3u);
     PH(0);  // wait for the record
     if (wv::any(valid && kind == 1)) {
       team_wait(ts + S_F8 + F8_WO, gstep);
@@ -1936,7 +1936,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     const int slot = x & 1;
     const int tile = tile_of(ts, g, x);
     const unsigned info = wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g);
-    const int kind = (int)(info & 0xffu), i16mode = (int)((info >> 8) & 0xffu);
+    const int kind = (int)(info & 3u), i16mode = (int)((info >> 8) & 3u);
     PH(0);  // wait for the record
 
     // (the bottom luma lines of the band above are in row 0's ring: FRONT fetched them)
