@@ -195,7 +195,7 @@ constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 #ifndef DRYV_BAND_PRIO_MODES
 #define DRYV_BAND_PRIO_MODES 3
 #endif
-constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a progress word (about a second) before a band gives up
+constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a hand-off record / progress word (about a second) before a band gives up
 constexpr unsigned TASK_END = 0xFFFFFFFFu;
 
 // Analysis only (tools/band_ablate.sh): -DDRYV_BAND_EXP_SKIP=<mask> drops phase k of the step (bit k) so that the difference
@@ -925,7 +925,8 @@ WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned known
 //                    reported here (status bit 0) and reads as kind 3 / qp 0 from then on
 //       word 6       chain rounds of the macroblock that have a DC-predicted block (bit t)
 //       word 7       the raw modes of its bottom grid row (DC for any other macroblock kind): neighbour B of the row below
-//     written through (sc1) and published per band by one progress word (progM = W) for the band below; the band's own
+//     written through (sc1) and published per band by one progress word (progM: the last row's macroblocks whose records are
+//     there; batch by batch for wide pictures, else W at the end) for the band below; the band's own
 //     steps load them back one step ahead, like the records.
 constexpr int MREC_WORDS = 8;
 template <bool HAS_I8>
@@ -2036,7 +2037,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       wv::wave_sync();
       PH(2);  // Intra16x16
 
-      PH(3);  // top-right copy, publish
+      PH(3);  // (nothing left here: the publication of the progress word went with the tagged hand-off records)
       const bool anyI4 = !EXP_SKIP(4) && wv::any(valid && kind == 0);
 
       // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================

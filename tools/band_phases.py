@@ -23,7 +23,7 @@ PHASES = {
               "-", "wait for the mode pre-pass (per task, here per step)"],
     "CHROMA": ["task+prologue", "hand-off traffic", "chroma residuals+prefetch", "chroma prediction", "lines+copies+flush",
                "mode pre-pass of the task (here per step)"],
-    "BACK": ["wait for record", "top border", "intra16x16", "top-right+publish", "intra4x4 chain", "line+copies+flush",
+    "BACK": ["wait for record", "top border", "intra16x16", "(publish: gone)", "intra4x4 chain", "line+copies+flush",
              "wait for BACK8"],
     "BACK8": ["wait for record", "wait for BACK's write-out of the step before", "top border + four Intra8x8 blocks"],
 }
