@@ -27,10 +27,10 @@
 //     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running, done, or some
 //     team's next task, so there is no deadlock at any residency. FRONT claims a team's next task DRYV_BAND_CLAIM_AHEAD
 //     steps before the current one ends, so that CHROMA -- ahead of the luma waves inside a task -- has it in time.
-//   * Between bands the hand-off goes through memory, in records of its own (Args::handoff), as 16-byte granules that
-//     carry their own tag (MI355X_MICROARCH.md: data-tagged granules, written through by one lane, observed untorn):
-//     {8 pixels of the last row's bottom line, the launch's generation, 0}, two for luma (BACK stores, the FRONT of the
-//     band below fetches), one each for Cb and Cr (CHROMA). A granule is there when its tag is: no progress word, no wait
+//   * Between bands the hand-off goes through memory, in records of its own (Args::handoff), as 8-byte granules that
+//     carry their own tag (cdna_hip_programming.md Guideline 16, R2: the data is the flag; one aligned 8-byte sc1 store,
+//     one 8-byte sc1 load): {4 pixels of the last row's bottom line, the launch's generation}, four for luma (BACK stores,
+//     the FRONT of the band below fetches), two each for Cb and Cr (CHROMA). A granule is there when its tag is: no progress word, no wait
 //     for the stores on the producer's side, one load per step (issued a step ahead) on the consumer's; a stale tag means
 //     poll. The records are zeroed once per workspace layout, and a generation is never reused. Only the mode records
 //     (CHROMA's pre-pass) keep a flag per band: sc1 stores, drained, then the flag.
@@ -268,8 +268,8 @@ struct Args {
   uint8_t* yuv;
   unsigned* status;     // [0] bit 0 unsupported record, bit 1 a block beyond the fast build's arithmetic, bit 2 a band gave up waiting;
                         // [1..3] where it gave up; [4] ~(sequence number of the first queued batch that raised bit 1)
-  unsigned* handoff;    // [frame][band that has a band below][mb][16]: the bottom lines of the band's last row, in four 16-byte
-                        // granules {8 pixels, tag, 0}: luma 0..7, luma 8..15, Cb, Cr. tag = gen: a granule is there when its tag is
+  unsigned* handoff;    // [frame][band that has a band below][mb][16]: the bottom lines of the band's last row, in eight 8-byte
+                        // granules {4 pixels, tag}: four of luma, two of Cb, two of Cr. tag = gen: a granule is there when its tag is
   unsigned gen;         // the launch's generation (never 0, never repeated over the life of the workspace)
   unsigned* progM;      // [frame][band]: W once the band's mode records (below) are visible
   unsigned* rowModes;   // [mb][8]: the mode record of every macroblock (MREC_*), written by the band's mode pre-pass
@@ -856,23 +856,22 @@ WV void team_wait_ge(int addr, unsigned want) {
 }
 
 constexpr int HAND_WORDS = 16;   // dwords per macroblock of the hand-off records (Args::handoff)
-// The hand-off record of a macroblock of the band above, eight lanes (li = 0..7) reading one dword each of the two
-// granules at dword offset `off` of the record (luma: 0, chroma: 8): dwords 0, 1 / 4, 5 the pixels, 2 / 6 the tags. `v`: what
-// the lanes requested a step ago (or just now). Polls -- all eight lanes again, a granule is written whole -- until both tags
-// are there (bounded: see SPIN_LIMIT).
-WV unsigned await_granules(const unsigned* rec, unsigned v, bool fetchLane, int li, unsigned tag, unsigned* status, unsigned task, int s,
-                           int lane) {
+// The hand-off record of a macroblock of the band above: four lanes (li = 0..3) read one 8-byte granule each, {four pixels,
+// tag} (luma: the bottom line's four quarters; chroma: Cb, Cb, Cr, Cr). `v`: what the lanes requested a step ago (or just
+// now). Polls -- the lanes whose tag is not there yet again -- until every tag is (bounded: see SPIN_LIMIT).
+WV unsigned long long await_granules(const unsigned long long* rec, unsigned long long v, bool fetchLane, unsigned tag, unsigned* status,
+                                     unsigned task, int s, int lane) {
   unsigned spins = 0;
-  while (wv::any(fetchLane && (li & 3) == 2 && v != tag)) {
+  while (wv::any(fetchLane && (unsigned)(v >> 32) != tag)) {
     wv::sleep_short();
-    if (fetchLane) v = wv::ld_sc1(rec);
+    if (fetchLane && (unsigned)(v >> 32) != tag) v = wv::ld_sc1_64(rec);
     if (++spins > SPIN_LIMIT) {
       // every spin is bounded: a band above that never gets there is reported (status bit 2 + where), not waited for
       if (lane == 0) {
         wv::atomic_or(status, 4u);
         status[1] = task;
         status[2] = ((unsigned)s << 16) | 0xffffu;
-        status[3] = v;
+        status[3] = (unsigned)(v >> 32);
       }
       break;
     }
@@ -1223,7 +1222,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     load_coefs_luma(0, kN1);
 
     PH(0);  // claim, prologue loads
-    unsigned lineN = 0;      // this lane's dword of the band above's hand-off record of macroblock s+1, requested during the previous step
+    unsigned long long lineN = 0;   // this lane's granule of the band above's hand-off record of macroblock s+1, requested during the previous step
 
     for (int s = 0; s < nSteps; s++, gstep++) {
       TRACE(1, s + 1);
@@ -1312,17 +1311,19 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       }
       PH(2);  // luma residuals
       // ---- hand-off traffic, placed here so that nothing in front of the residuals waits for it.
-      // lanes 0..7: the two luma granules of macroblock s+1 of the band above's last row (a dword each); lanes 16..23: of
-      // macroblock 0 at step 0. A granule carries its own tag: no progress word, no ordering between the band above's stores.
+      // lanes 0..3: the four luma granules of macroblock s+1 of the band above's last row; lanes 16..19: of macroblock 0 at
+      // step 0. A granule carries its own tag: no progress word, no ordering between the band above's stores.
       // Macroblock s+2 is requested now and looked at in the next step: the request has a whole step to come back.
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
-      const bool fetchLane = needUp && li < 8 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+      const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
       if (needUp && !EXP_SKIP(2)) {
-        const unsigned* const rec = handUp + (HAND_WORDS * mbx + li);
-        if (fetchLane) lineV = (s > 0 && lane < 16) ? lineN : wv::ld_sc1(rec);
-        lineV = await_granules(rec, lineV, fetchLane, li, A.gen, A.status, task, s, lane);
-        if (lane < 8 && s + 2 < W) lineN = wv::ld_sc1(rec + HAND_WORDS);
+        const unsigned long long* const rec = (const unsigned long long*)handUp + ((HAND_WORDS / 2) * mbx + li);
+        unsigned long long g64 = 0;
+        if (fetchLane) g64 = (s > 0 && lane < 16) ? lineN : wv::ld_sc1_64(rec);
+        g64 = await_granules(rec, g64, fetchLane, A.gen, A.status, task, s, lane);
+        lineV = (unsigned)g64;
+        if (lane < 4 && s + 2 < W) lineN = wv::ld_sc1_64(rec + HAND_WORDS / 2);
       }
       if (HAS_I8 || EXP_SKIP(0) || EXP_DUP_IS(0)) load_coefs_luma(s + 1, kN1);  // (otherwise: requested inside the residual pass)
       PH(3);  // hand-off traffic, coefficient prefetch
@@ -1364,7 +1365,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         wv::lds_st32(ts + S_INFO + 32 * buf + 28, 0u);  // rounds of the block chain that have a DC block: below
       }
       // what was fetched from the band above goes into row 0's luma ring (BACK's)
-      if (fetchLane && (li & 2) == 0) wv::lds_st32(ringy(ts, 0, mbx, (int)(seq & 1u)) + 4 * ((li & 1) | ((li >> 2) << 1)), lineV);
+      if (fetchLane) wv::lds_st32(ringy(ts, 0, mbx, (int)(seq & 1u)) + 4 * li, lineV);
       wv::wave_sync();
       // the step's modes from the band's pre-pass (band_modes): words 0..5 of the macroblock's mode record are the table
       // rows of BACK's block chain (S_MSEQ), word 6 the chain rounds that have a DC block -- BACK skips the DC arithmetic
@@ -1484,7 +1485,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     for (int k = 0; k < 8; k++) rB[k] = 0;
     load_coefs_chroma(0);
     PH(0);  // task, prologue loads
-    unsigned lineN = 0;      // this lane's dword of the band above's hand-off record of macroblock s+1, requested during the previous step
+    unsigned long long lineN = 0;   // this lane's granule of the band above's hand-off record of macroblock s+1, requested during the previous step
 
     for (int s = 0; s < nSteps; s++) {
       const bool evenStep = (s & 1) == 0;
@@ -1512,16 +1513,18 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       // dC: the residual lane's macroblock (of its step of the pair); dEven / dOdd: the prediction lane's (of this step)
       const int kindR = (int)(dC & 3u), qpR = (int)(dC >> 24);
 
-      // ---- hand-off traffic. lanes 0..7: the two chroma granules (Cb, Cr) of macroblock s+1 of the band above (a dword
-      // each); lanes 16..23: of macroblock 0 at step 0; macroblock s+2 is requested a step early (as in FRONT)
+      // ---- hand-off traffic. lanes 0..3: the four chroma granules (Cb, Cb, Cr, Cr) of macroblock s+1 of the band above;
+      // lanes 16..19: of macroblock 0 at step 0; macroblock s+2 is requested a step early (as in FRONT)
       const int li = lane & 15;
       const int mbx = lane < 16 ? s + 1 : 0;
-      const bool fetchLane = needUp && li < 8 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
+      const bool fetchLane = needUp && li < 4 && (lane < 16 ? s + 1 < W : (lane < 32 && s == 0));
       if (needUp && !EXP_SKIP(9)) {
-        const unsigned* const rec = handUp + (HAND_WORDS * mbx + 8 + li);
-        if (fetchLane) lineV = (s > 0 && lane < 16) ? lineN : wv::ld_sc1(rec);
-        lineV = await_granules(rec, lineV, fetchLane, li, A.gen, A.status, task, s, lane);
-        if (lane < 8 && s + 2 < W) lineN = wv::ld_sc1(rec + HAND_WORDS);
+        const unsigned long long* const rec = (const unsigned long long*)handUp + ((HAND_WORDS / 2) * mbx + 4 + li);
+        unsigned long long g64 = 0;
+        if (fetchLane) g64 = (s > 0 && lane < 16) ? lineN : wv::ld_sc1_64(rec);
+        g64 = await_granules(rec, g64, fetchLane, A.gen, A.status, task, s, lane);
+        lineV = (unsigned)g64;
+        if (lane < 4 && s + 2 < W) lineN = wv::ld_sc1_64(rec + HAND_WORDS / 2);
       }
       PH(1);  // hand-off traffic
 
@@ -1567,7 +1570,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         load_coefs_chroma(s + 2);
         kN1 = load_kind(s + 2);
       }
-      if (fetchLane && (li & 2) == 0) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * ((li & 1) | ((li >> 2) << 1)), lineV);
+      if (fetchLane) wv::lds_st32(ts + S_RINGC + RINGC_ENT * (mbx & 3) + 4 * li, lineV);
       wv::wave_sync();
       PH(2);  // chroma residuals, prefetch
 
@@ -1682,10 +1685,10 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         if (i < 4) v = wv::lds_u32(aBot + 8 * slot);
         if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(aRing + RINGC_ENT * (x & 3), v);
         if (hasBelow && wv::any(valid && g == gl)) {
-          // the band's last row: a granule per plane {8 pixels, tag, 0} into the hand-off record, written through (lanes 0 / 2
-          // of the row: Cb / Cr, whose first dword v is; the second is the next lane's)
-          const unsigned v1 = (unsigned)wv::dppx<DPP_ROW_SHL(1)>((int)v);
-          if (valid && g == gl && (i == 0 || i == 2)) wv::st_g128_sc1(handMy + (HAND_WORDS * x + 8 + 2 * i), u32x4{v, v1, A.gen, 0u});
+          // the band's last row: a granule {4 pixels, tag} per lane into the hand-off record (lanes 0..3 of the row: Cb, Cb, Cr,
+          // Cr), each ONE aligned 8-byte write-through store: the tag arrives with the pixels
+          if (valid && g == gl && i < 4)
+            wv::st_sc1_64((unsigned long long*)handMy + ((HAND_WORDS / 2) * x + 4 + i), (unsigned long long)v | ((unsigned long long)A.gen << 32));
         }
       }
       // left neighbour copy: chroma column 7
@@ -2172,11 +2175,12 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         if (i < 4) v = wv::lds_u32(tile + TILE_STRIDE * 16 + 8 + 16 * slot + 4 * i);
         if (valid && i < 4 && g < 3 && g < gl) wv::lds_st32(ringy(ts, g + 1, x, par) + 4 * i, v);
         if (hasBelow && wv::any(valid && g == gl)) {
-          // the band's last row: two granules {8 pixels, tag, 0} into the hand-off record, written through (lanes 0 / 2 of the
-          // row, whose dword v is the granule's first; the second is the next lane's). The tag travels with the pixels: the
-          // band below needs no progress word, and this wave no wait for its stores.
-          const unsigned v1 = (unsigned)wv::dppx<DPP_ROW_SHL(1)>((int)v);
-          if (valid && g == gl && (i == 0 || i == 2)) wv::st_g128_sc1(handMy + (HAND_WORDS * x + 2 * i), u32x4{v, v1, A.gen, 0u});
+          // the band's last row: a granule {4 pixels, tag} per lane into the hand-off record (lanes 0..3 of the row), each ONE
+          // aligned 8-byte write-through store (MI355X_MICROARCH.md / cdna_hip_programming.md Guideline 16, R2: the data is
+          // the flag). The tag travels with the pixels: the band below needs no progress word, and this wave no wait for its
+          // stores.
+          if (valid && g == gl && i < 4)
+            wv::st_sc1_64((unsigned long long*)handMy + ((HAND_WORDS / 2) * x + i), (unsigned long long)v | ((unsigned long long)A.gen << 32));
         }
       }
       // left neighbour copy: luma column 15 (also the tile's x = -1 border when the next macroblock is slot 0)

@@ -126,6 +126,9 @@ WV unsigned alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_a
 // ---- global memory ------------------------------------------------------------------------------------
 WV unsigned ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV void st_sc1(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one aligned 8-byte relaxed agent-scope access (global_load / store_dwordx2 sc1): a data-tagged granule is one of these
+WV unsigned long long ld_sc1_64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV void st_sc1_64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV unsigned atomic_add_task(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 WV void atomic_or(unsigned* p, unsigned v) { atomicOr(p, v); }
 WV void atomic_max(unsigned* p, unsigned v) { atomicMax(p, v); }

@@ -176,6 +176,8 @@ WV unsigned alignbit(unsigned hi, unsigned lo, unsigned sh) {
 
 WV unsigned ld_sc1(const unsigned* p) { return *(const volatile unsigned*)p; }
 WV void st_sc1(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
+WV unsigned long long ld_sc1_64(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
+WV void st_sc1_64(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
 WV unsigned atomic_add_task(unsigned* p, unsigned v) { const unsigned o = *p; *p += v; return o; }
 WV void atomic_or(unsigned* p, unsigned v) { *p |= v; }
 WV void atomic_max(unsigned* p, unsigned v) { if (v > *p) *p = v; }
