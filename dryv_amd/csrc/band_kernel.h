@@ -161,6 +161,12 @@ WV int ringy(int ts, int g, int e, int par) {
   return g == 0 ? ts + S_RINGY + 128 * par + 16 * (e & 7) : ts + S_RINGY + 256 + 64 * (g - 1) + 16 * (e & 3);
 }
 
+// Which wave derives a band's prediction modes before its first step. Without the 8x8 transform: FRONT itself (-1.7 % on the
+// 300-picture batch: it stood waiting for CHROMA, the wave that finishes a task last, 55 us per task; the pre-pass is 16 us).
+// With it: CHROMA (FRONT carries the 8x8 residuals there and is the later one: +1.6 % on the 4K batch the other way round).
+#ifndef DRYV_BAND_MODES_IN_FRONT
+#define DRYV_BAND_MODES_IN_FRONT(hasI8) (!(hasI8))
+#endif
 #ifndef DRYV_BAND_I8_PK16
 #define DRYV_BAND_I8_PK16 1   // (0: the 8x8 residuals always in 32 bits -- A/B builds)
 #endif
@@ -238,15 +244,25 @@ constexpr unsigned TASK_END = 0xFFFFFFFFu;
 #endif
 // -DDRYV_BAND_TIMELINE (tools/band_timeline.py): per band task, 100 MHz timestamps of the claim (FRONT) and of BACK's
 // first and last step, behind the trace records
+// (with -DDRYV_BAND_TLMODES as well, tools/modes_timeline.py: the four stamps are the mode pre-pass's instead -- its start, the
+// end of its first wait for the band above, its end, and FRONT's arrival at the wait for it)
 #if defined(DRYV_BAND_TIMELINE) && !defined(DRYV_EMU)
-#define TLINE(task, k, val)                                                                                   \
+#define TLINE_(task, k, val)                                                                                  \
   do {                                                                                                        \
-    if (lane0 == 0 && A.profile)                                                                              \
+    if (wv::lane_id() == 0 && A.profile)                                                                      \
       (A.profile + (size_t)65536 * (BAND_NPH + 4))[(size_t)(task) * 4 + (k)] = (unsigned long long)(val);   \
   } while (0)
 #define TNOW() __builtin_amdgcn_s_memrealtime()
+#ifdef DRYV_BAND_TLMODES
+#define TLINE(task, k, val) do { } while (0)
+#define TLM(task, k, val) TLINE_(task, k, val)
+#else
+#define TLINE(task, k, val) TLINE_(task, k, val)
+#define TLM(task, k, val) do { } while (0)
+#endif
 #else
 #define TLINE(task, k, val) do { } while (0)
+#define TLM(task, k, val) do { } while (0)
 #define TNOW() 0
 #endif
 // breadcrumbs: word k of this wave's 8-word trace record (behind the phase sums), written through so that a host
@@ -935,6 +951,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
   const int W = P.W;
   unsigned upKnownM = 0;   // macroblocks of the band above's last row whose records are known to be there
   const bool perBatch = W > 128;
+  TLM(task, 0, TNOW());
   if (lane < 4) wv::lds_st32(ts + S_CARRYM + 4 * lane, 0x02020202u);
   wv::wave_sync();
   // One iteration = 64 macroblocks of one row: batch after batch, the band's rows inside a batch (row g's neighbour B
@@ -959,6 +976,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
     // drain cost 1 % and overlap nothing; 240 wide, four batches: -1.7 %)
     if (G.hasAbove && g == 0)
       upKnownM = poll_progress(upProgM, upProgM, upKnownM, (unsigned)(perBatch ? min(x0 + 64, W) : W), (unsigned)W, A.status, task, -1, lane);
+    if (it == 0) TLM(task, 1, TNOW());
     const int x = x0 + lane;
     const bool valid = x < W;
     const bool xIs0 = x == 0, xLast = x + 1 >= W;
@@ -1104,6 +1122,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
     }
   }
   wv::wait_vm(0);
+  TLM(task, 2, TNOW());
 }
 
 // ==================================================================================================================
@@ -1179,9 +1198,20 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     const unsigned* const handUp = A.handoff + ((size_t)G.f * (nBands - 1) + (G.b - 1)) * (size_t)W * HAND_WORDS;
     const int claimStep = max(nSteps - DRYV_BAND_CLAIM_AHEAD, 0);
 
-    // the band's prediction modes, all of them, are derived before its first step (CHROMA: band_modes)
-    team_wait_ge(ts + S_FLAGS + F_MODES, seq + 1);
-    PH(6);  // wait for the mode pre-pass
+    // ---- the band's prediction modes, all of them, before its first step (band_modes), by this wave: CHROMA, which derived
+    // them until the end of round 3, is the wave that finishes a task last (tools/modes_timeline.py: FRONT stood here 55 us
+    // per task, 13 % of it, most of the time before CHROMA had even begun); the pre-pass itself is 16 us
+    TLM(task, 3, TNOW());
+    if (DRYV_BAND_MODES_IN_FRONT(HAS_I8)) {
+      unsigned* const myProgM = A.progM + (size_t)G.f * nBands + G.b;
+      wv::setprio<DRYV_BAND_PRIO_MODES>();
+      EXP_REP(10) band_modes<HAS_I8>(P, A, G, task, ts, (const uint8_t*)(A.mbs + mbFrame), A.rowModes + mbFrame * MREC_WORDS, myProgM - 1, myProgM);
+      wv::setprio<(HAS_I8 ? DRYV_BAND_PRIO_FRONT_I8 : DRYV_BAND_PRIO_FRONT)>();
+      if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_MODES, seq + 1);   // (CHROMA reads the records too)
+    } else {
+      team_wait_ge(ts + S_FLAGS + F_MODES, seq + 1);
+    }
+    PH(6);  // mode pre-pass (or the wait for it)
 
     // ---- software pipeline: a step's record is fetched one step ahead (its first word, which decides the
     // coefficient layout, two steps ahead); its coefficients are fetched right after the previous step's residual
@@ -1443,14 +1473,16 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
 
     // ---- the band's prediction modes, all of them, before its first step: FRONT hands a task over well before the luma
     // waves get to it, and this wave, ahead of them inside a task, has the time (band_modes)
-    {
+    if (DRYV_BAND_MODES_IN_FRONT(HAS_I8)) {
+      team_wait_ge(ts + S_FLAGS + F_MODES, seq + 1);   // (FRONT derives them)
+    } else {
       unsigned* const myProgM = A.progM + (size_t)G.f * nBands + G.b;
       wv::setprio<DRYV_BAND_PRIO_MODES>();
       EXP_REP(10) band_modes<HAS_I8>(P, A, G, task, ts, mbsF, recF, myProgM - 1, myProgM);
       wv::setprio<DRYV_BAND_PRIO_CHROMA>();
       if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_MODES, seq + 1);
     }
-    PH(5);  // mode pre-pass
+    PH(5);  // mode pre-pass (or the wait for it)
 
     // Residuals are computed for two steps at a time, lanes 0..31 the even step's 32 blocks, lanes 32..63 the odd step's
     // (a residual pass costs the same for 32 lanes as for 64); prediction then runs on the half whose step it is.
