@@ -13,9 +13,7 @@ from resource_usage import resource_usage  # noqa: E402
 
 # build -> (VGPRs at most, waves per SIMD at least, spilled VGPRs at most, scratch bytes per lane at most)
 DOCUMENTED = {
-    # the bench configuration (no 8x8 transform): three lane constants of CHROMA live in scratch (stored once per wave,
-    # re-read in the step loop) since the mode records leave through LDS as whole lines -- which is 3-4 % faster all the same
-    "void dryv::band_kernel<false, false>": (80, 6, 3, 16),
+    "void dryv::band_kernel<false, false>": (80, 6, 0, 0),     # the bench configuration: no 8x8 transform
     "void dryv::band_kernel<true, false>": (96, 5, 0, 0),      # streams with the 8x8 transform
     "void dryv::band_kernel<false, true>": (128, 4, 0, 0),     # WIDE builds: re-run of a flagged batch only
     "void dryv::band_kernel<true, true>": (128, 4, 0, 0),
