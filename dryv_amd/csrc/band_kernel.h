@@ -167,6 +167,9 @@ WV int ringy(int ts, int g, int e, int par) {
 #ifndef DRYV_BAND_MODES_IN_FRONT
 #define DRYV_BAND_MODES_IN_FRONT(hasI8) (!(hasI8))
 #endif
+#ifndef DRYV_BAND_CHROMA_TRAIL
+#define DRYV_BAND_CHROMA_TRAIL 4
+#endif
 #ifndef DRYV_BAND_I8_PK16
 #define DRYV_BAND_I8_PK16 1   // (0: the 8x8 residuals always in 32 bits -- A/B builds)
 #endif
@@ -253,7 +256,11 @@ constexpr unsigned TASK_END = 0xFFFFFFFFu;
       (A.profile + (size_t)65536 * (BAND_NPH + 4))[(size_t)(task) * 4 + (k)] = (unsigned long long)(val);   \
   } while (0)
 #define TNOW() __builtin_amdgcn_s_memrealtime()
-#ifdef DRYV_BAND_TLMODES
+#if defined(DRYV_BAND_TLENDS)   // (tools/ends_timeline.py: when FRONT, BACK and CHROMA finish a task, and when CHROMA begins it)
+#define TLINE(task, k, val) do { } while (0)
+#define TLM(task, k, val) do { } while (0)
+#define TLE(task, k, val) TLINE_(task, k, val)
+#elif defined(DRYV_BAND_TLMODES)
 #define TLINE(task, k, val) do { } while (0)
 #define TLM(task, k, val) TLINE_(task, k, val)
 #else
@@ -264,6 +271,9 @@ constexpr unsigned TASK_END = 0xFFFFFFFFu;
 #define TLINE(task, k, val) do { } while (0)
 #define TLM(task, k, val) do { } while (0)
 #define TNOW() 0
+#endif
+#ifndef TLE
+#define TLE(task, k, val) do { } while (0)
 #endif
 // breadcrumbs: word k of this wave's 8-word trace record (behind the phase sums), written through so that a host
 // thread can read them while the kernel is still running
@@ -1409,6 +1419,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       PH(4);  // record for BACK
     }
     if (!claimedNext) nextTask = claim_push(seq + 1);
+    TLE(task, 0, TNOW());
     TRACE(6, task + 1u);
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
@@ -1453,6 +1464,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
   const int fseg2 = wv::opaque(2 * fseg);   // 2 * segment
   // the band above's bottom lines (lanes 0..1 of a row group Cb, 2..3 Cr): + (8 * r0 - 1) * pitchC + 8 * macroblock
 
+  unsigned gstepC = 0;   // this wave's steps so far (BACK's count of them is in the team's F_FREE words)
   for (unsigned seq = 0;; seq++) {
     team_wait_ge(ts + S_FLAGS + F_HEAD, seq + 1);
     const unsigned task = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_FLAGS + F_TASKS + 4 * (int)(seq & 3u)));
@@ -1483,6 +1495,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_MODES, seq + 1);
     }
     PH(5);  // mode pre-pass (or the wait for it)
+    TLE(task, 3, TNOW());
 
     // Residuals are computed for two steps at a time, lanes 0..31 the even step's 32 blocks, lanes 32..63 the odd step's
     // (a residual pass costs the same for 32 lanes as for 64); prediction then runs on the half whose step it is.
@@ -1519,8 +1532,16 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     PH(0);  // task, prologue loads
     unsigned long long lineN = 0;   // this lane's granule of the band above's hand-off record of macroblock s+1, requested during the previous step
 
-    for (int s = 0; s < nSteps; s++) {
+    for (int s = 0; s < nSteps; s++, gstepC++) {
       const bool evenStep = (s & 1) == 0;
+      // This wave is the one that finishes a task last (tools/ends_timeline.py: 60 ... 90 us behind BACK, and the launch ends
+      // when the last CHROMA does). Priority by how far behind BACK it is (BACK's step count: the record it freed last):
+      // one above FRONT's when it trails by more than DRYV_BAND_CHROMA_TRAIL steps, FRONT's otherwise.
+      if (DRYV_BAND_CHROMA_TRAIL >= 0 && evenStep) {
+        const unsigned bs = max(wv::lds_u32(ts + S_FLAGS + F_FREE), wv::lds_u32(ts + S_FLAGS + F_FREE + 4));
+        if ((int)((unsigned)wv::rfl((int)bs) - gstepC) > DRYV_BAND_CHROMA_TRAIL) wv::setprio<DRYV_BAND_PRIO_BACK>();
+        else wv::setprio<DRYV_BAND_PRIO_CHROMA>();
+      }
       if (evenStep) {
         dC = kN1;   // (checked by band_modes: an unsupported record reads as kind 3 / qp 0 and reconstructs as zero)
       }
@@ -1767,6 +1788,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       wv::wave_sync();
       PH(4);  // chroma lines, copies, flush
     }
+    TLE(task, 2, TNOW());
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
   if (lane0 == 0 && A.profile)
@@ -2245,6 +2267,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       if (HAS_I8 && lane == 0) wv::lds_st32(ts + S_F8 + F8_WO, gstep + 1);  // BACK8 may start the next step
       PH(5);  // line, copies, flush
       if (s == G.nSteps - 1) TLINE(task, 2, TNOW());
+      if (s == G.nSteps - 1) TLE(task, 1, TNOW());
   }
 #if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
   if (lane0 == 0 && A.profile)
