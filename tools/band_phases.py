@@ -20,9 +20,9 @@ from dryv_amd import _build, abi, synth  # noqa: E402
 ROLES = ["FRONT", "BACK", "CHROMA", "BACK8"]   # wave w of a team: role w % 3 (w % 4 in builds with the 8x8 transform; recon_band.hip)
 PHASES = {
     "FRONT": ["claim+prologue", "record decode", "luma residuals", "hand-off+prefetch", "record for BACK (incl. wait for a free buffer)",
-              "-", "wait for the mode pre-pass (per task, here per step)"],
+              "-", "mode pre-pass (8x8 builds: the wait for CHROMA's) (per task, here per step)"],
     "CHROMA": ["task+prologue", "hand-off traffic", "chroma residuals+prefetch", "chroma prediction", "lines+copies+flush",
-               "mode pre-pass of the task (here per step)"],
+               "wait for FRONT's mode pre-pass (8x8 builds: the pre-pass) (here per step)"],
     "BACK": ["wait for record", "top border", "intra16x16", "(publish: gone)", "intra4x4 chain", "line+copies+flush",
              "wait for BACK8"],
     "BACK8": ["wait for record", "wait for BACK's write-out of the step before", "top border + four Intra8x8 blocks"],
