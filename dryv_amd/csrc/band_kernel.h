@@ -17,8 +17,12 @@
 //               other. Two more LDS words: BACK8 -> BACK "the step's Intra8x8 macroblocks are in the tiles", BACK ->
 //               BACK8 "the step's write-out (left columns, line rings, tile borders) is through";
 //       CHROMA  all of chroma (residuals, prediction, staging, stores, hand-off): nothing in it depends on a luma
-//               pixel or on the other two waves -- and, between two tasks, the next band's prediction modes (band_modes:
-//               a pre-pass over the whole band, one lane per macroblock).
+//               pixel or on the other two waves.
+//     A band's prediction modes are derived before its first step by a pre-pass over the whole band, one lane per
+//     macroblock (band_modes): by FRONT in the builds without the 8x8 transform, by CHROMA (between two tasks) with it
+//     -- whichever is not the wave that finishes a task last (DRYV_BAND_MODES_IN_FRONT). The waves' priorities follow
+//     who is behind: CHROMA takes BACK's while it trails BACK by more than a few steps (DRYV_BAND_CHROMA_TRAIL), FRONT
+//     (8x8 builds) while its lead over BACK is short (DRYV_BAND_FRONT_LEAD).
 //     FRONT -> BACK coupling is the per-step record in LDS (residuals, table rows, macroblock kinds) and two LDS words
 //     per buffer (ready / free). A lone wave issues about one instruction every 4-5 cycles whatever its kind, so a
 //     step's latency is the instruction count of the slowest wave; the split cuts it, and with it the frame's critical
@@ -26,7 +30,7 @@
 //   * Bands come off one queue in band-major order (band 0 of every frame, band 1 of every frame, ...): a band's
 //     predecessor (same frame, band above) has a smaller number, was claimed earlier and is running, done, or some
 //     team's next task, so there is no deadlock at any residency. FRONT claims a team's next task DRYV_BAND_CLAIM_AHEAD
-//     steps before the current one ends, so that CHROMA -- ahead of the luma waves inside a task -- has it in time.
+//     steps before the current one ends, so that CHROMA has it when it gets there.
 //   * Between bands the hand-off goes through memory, in records of its own (Args::handoff), as 8-byte granules that
 //     carry their own tag (cdna_hip_programming.md Guideline 16, R2: the data is the flag; one aligned 8-byte sc1 store,
 //     one 8-byte sc1 load): {4 pixels of the last row's bottom line, the launch's generation}, four for luma (BACK stores,
@@ -120,7 +124,7 @@ constexpr int S_MSEQ = S_RES + NBUF * RES_BUF;   // u8  [NBUF][4][2][12]  8 x th
 constexpr int S_INFO = S_MSEQ + 96 * NBUF;       // u32 [NBUF][8]      kinds of the 4 macroblocks, Intra16x16 modes, task, step, parity, chain rounds with a DC block
 constexpr int S_FLAGS = S_INFO + 32 * NBUF;      // u32 ready[4], free[4] (global step count + 1 of the record in / consumed from the
                                  //     buffer), taskRing[4], taskHead, taskTailC (FRONT -> CHROMA: the claimed tasks),
-                                 //     modesDone (CHROMA -> FRONT: tasks whose mode pre-pass is through)
+                                 //     modesDone (the wave that derives the modes -> the other: tasks whose mode pre-pass is through)
 constexpr int F_READY = 0, F_FREE = 16, F_TASKS = 32, F_HEAD = 48, F_TAILC = 52, F_MODES = 56;
 // BACK (+ FRONT writes row 0 of the luma ring: lines fetched from the band above)
 constexpr int S_TILE = (S_FLAGS + 64 + 63) & ~63;  // u8  [4][NP][TILE_BYTES]  luma: tile (x >> 1) % NP, row j = y + 1, column 8 + 16 * (x & 1) + xr
@@ -149,7 +153,7 @@ constexpr int S_G8 = S_F8 + 64;        // FRONT: row-pass output. 32-bit passes:
                                        //           are that much larger); packed form: i16 [4][4 blk8][8][8] with S_C8's strides, the four
                                        //           column pairs of row r rotated by r >> 1 (rows written and columns read without conflicts)
 // builds without it append instead:
-constexpr int S_MREC = S_BYTES;        // [64][32]  CHROMA: the mode records of a pre-pass iteration, on their way to memory as whole lines (the 8x8
+constexpr int S_MREC = S_BYTES;        // [64][32]  FRONT: the mode records of a pre-pass iteration, on their way to memory as whole lines (the 8x8
                                        //           builds have no room for it: 5 x 31.4 KB per CU; theirs leave lane by lane)
 constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * C8_MB) : S_BYTES + 2048; }
 static_assert(S_CARRYM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
@@ -971,8 +975,8 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
   if (lane < 4) wv::lds_st32(ts + S_CARRYM + 4 * lane, 0x02020202u);
   wv::wave_sync();
   // One iteration = 64 macroblocks of one row: batch after batch, the band's rows inside a batch (row g's neighbour B
-  // is the same lane one iteration earlier). (No prefetch across iterations: the wave that runs this -- CHROMA, between
-  // two tasks -- is ahead of the luma waves, and the registers are worth more than the latency.)
+  // is the same lane one iteration earlier). (No prefetch across iterations: requesting the next record an iteration ahead
+  // measured 1.9 % slower.)
   const int nR = G.nR, nIter = ((W + 63) >> 6) * nR;
   auto mb_of = [&](int it) -> unsigned {   // this lane's macroblock in iteration `it` (the last one of the row beyond it)
     const int xb = it / nR, gg = it - xb * nR;
@@ -1179,9 +1183,9 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_HEAD, q + 1);
     return t;
   };
-  // A task is claimed CLAIM_AHEAD steps before the previous one ends: CHROMA, which runs ahead of the luma waves inside a
-  // task and used to wait for the next one, derives the next band's prediction modes (band_modes) in that time. (Any
-  // unfinished task with the smallest number is some team's current one and waits only for smaller ones: no deadlock.)
+  // A task is claimed CLAIM_AHEAD steps before the previous one ends, so that CHROMA, which follows the tasks through the
+  // team's ring, has the next one when it gets there (12 / 24 / 48 / 96 steps measure the same). (Any unfinished task
+  // with the smallest number is some team's current one and waits only for smaller ones: no deadlock.)
 #ifndef DRYV_BAND_CLAIM_AHEAD
 #define DRYV_BAND_CLAIM_AHEAD 24
 #endif
