@@ -74,14 +74,18 @@ constexpr int T_LS4Z = 0;     // u16 [6][16]    LevelScale4x4 in list order
 constexpr int T_QPC = 192;    // u8  [2][52]    QP'c for Cb / Cr as a function of QPY (transform.rs:194-216)
 constexpr int T_THR4 = 304;   // u16 [52]
 constexpr int T_THR8 = 408;   // u16 [52]
-constexpr int T_T4E = 512;    // u32 [8][12][2] Intra4x4 entries [pixel pair][mode][pixel]
-constexpr int T_LS4Q = 1280;  // u16 [52][16]   per qp: LevelScale4x4 << max(qp/6 - 4, 0) in list order, 0xFFFF where that needs 17 bits
-constexpr int T_LSMAX = 2944; // u16 [52]       per qp: the largest entry of its T_LS4Q row
-constexpr int T_QP = 3072;    // u32 [52][8]    per qp, what a 4x4 residual pass derives from it: [0] rounding term and [1] right shift
+constexpr int T_LS4Q = 512;   // u16 [52][16]   per qp: LevelScale4x4 << max(qp/6 - 4, 0) in list order, 0xFFFF where that needs 17 bits
+constexpr int T_LSMAX = 2176; // u16 [52]       per qp: the largest entry of its T_LS4Q row
+constexpr int T_QP = 2304;    // u32 [52][8]    per qp, what a 4x4 residual pass derives from it: [0] rounding term and [1] right shift
                               //                of the packed path (both halves), [2] T_LSMAX | T_THR4 << 16, [3] shl | rnd << 8 |
                               //                shr << 16 | (32 * (qp % 6)) << 24; DC terms: [4] LevelScale(0,0), [5] qp / 6,
                               //                [6] rounding term and [7] shl | shr << 8 of the Intra16x16 DC scaling
-constexpr int T_END = 4736;
+constexpr int T_T4W = 3968;   // u32 [8][17][4] the block chain's prediction table, [pixel pair][row]: {byte offset of an aligned 8-byte
+                              //                window of the block's edge array (S_EDGE), byte selector of the pair's left pixel, of its
+                              //                right pixel (v_perm_b32 on the window: four bytes whose sum + 2 >> 2 is the pixel; 0x0d0d0d0d:
+                              //                the block's DC), 0}. Rows: T4R_*
+constexpr int T4W_PAIR = 272;  // a pixel pair's 16 entries + 16: the pairs' entries of one row on different banks
+constexpr int T_END = 6144;
 constexpr int T_LS8 = T_END;          // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
 constexpr int T_T8 = T_LS8 + 768;     // u8  [9][64]    Intra8x8 table [mode][y*8+x]: byte offset of the sample in S_E8 (4 * position + which of E1 / F / G)
 constexpr int T_ZZ8 = T_T8 + 576;     // u8  [64]       8x8 list index -> 2 * raster position
@@ -93,6 +97,25 @@ constexpr int T_THR8P = T_ZZ8P + 64;  // u16 [52]       per qp: the largest sum 
                                       //                exact (0: none)
 constexpr int T_END_I8 = T_THR8P + 128;
 static_assert(T_END % 64 == 0 && T_END_I8 % 64 == 0, "table layout");
+
+// The block chain's table rows (T_T4W; a mode record holds 16 x the row): the nine Intra4x4 modes of 8.3.1.2 by number
+// (DC = 2: both neighbours there), and
+constexpr int T4R_DC = 2;
+constexpr int T4R_ZERO = 9;      // zero prediction: quirk Q4 (reference samples missing), an unsupported record
+constexpr int T4R_NOTR3 = 10;    // modes 3 / 7 without a top-right block: T4..T7 := T3
+constexpr int T4R_NOTR7 = 11;
+constexpr int T4R_DC_TOP = 12;   // DC with the top neighbour alone
+constexpr int T4R_DC_LEFT = 13;  // DC with the left neighbour alone; with neither: the left column then reads 128 (band_back)
+constexpr int T4R_H16 = 14;      // Intra16x16 horizontal: the macroblock's left column, four samples per block row, in the T0..T3 bytes
+constexpr int T4R_PRED16 = 15;   // Intra16x16 DC and plane: the block's sixteen predicted pixels ARE its edge array, [y][x] (Intra16x16
+                                 // vertical = row 0 on the macroblock's top line)
+// A block's edge array (S_EDGE, 16 bytes): everything its prediction reads, gathered where the neighbours' pixels are written
+constexpr int E_DUMP = 0;        // (bytes 0, 1: where lanes that have nothing to scatter write)
+constexpr int E_L3 = 3;          // L3 L2 L1 L0 (left column, bottom to top), corner, T0..T3, T4..T7 (top-right)
+constexpr int E_CORNER = 7, E_T0 = 8, E_T4 = 12;
+constexpr int E_SLOT = 16;
+constexpr int E_ROW = 20 * E_SLOT;   // a row group's blocks 4 * by + bx, by = 0..4 (row 4: where the last block row's scatter lands);
+                                     // 320 = 64 banks + 16: the four row groups' blocks of a round sit on different banks
 
 // ---- per-team scratch in LDS (byte offsets from the team's base) ---------------------------------------------
 // Output staging: a row's pixels are flushed to global memory NSY (luma) / NSC (chroma) macroblocks at a time, as
@@ -137,7 +160,9 @@ constexpr int RINGC_ROW = 64, RINGC_ENT = 16;
 constexpr int S_LEFTC = S_RINGC + 256;            // u8 [4][2][8]
 // FRONT
 constexpr int S_CARRYM = S_LEFTC + 64;            // u32 [4]     mode pre-pass: right-column modes of the macroblock left of the batch, per row
-constexpr int S_BYTES = (S_CARRYM + 64 + 63) & ~63;
+// BACK
+constexpr int S_EDGE = S_CARRYM + 64;             // u8 [4][20][16]  the edge arrays (E_*) of the step's macroblocks, a row group every E_ROW
+constexpr int S_BYTES = (S_EDGE + 4 * E_ROW + 4 * E_SLOT + 63) & ~63;   // (+ 4 slots: the dump bytes reach that far beyond the last row group's)
 // builds that serve the 8x8 transform (HAS_I8) append, per team:
 constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order (the packed form:
                                        //           pair-interleaved, T_ZZ8P); a block every C8_BLK bytes, a macroblock every C8_MB: the
@@ -156,7 +181,7 @@ constexpr int S_G8 = S_F8 + 64;        // FRONT: row-pass output. 32-bit passes:
 constexpr int S_MREC = S_BYTES;        // [64][32]  FRONT: the mode records of a pre-pass iteration, on their way to memory as whole lines (the 8x8
                                        //           builds have no room for it: 5 x 31.4 KB per CU; theirs leave lane by lane)
 constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * C8_MB) : S_BYTES + 2048; }
-static_assert(S_CARRYM + 64 <= S_BYTES && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
+static_assert(S_EDGE % 16 == 0 && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
 // the luma tile of macroblock x of row g
@@ -360,27 +385,40 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
     wv::lds_st32(ldsBase + T_QP + 32 * qp + 24, qd < 6 ? 1u << (5 - qd) : 0u);
     wv::lds_st32(ldsBase + T_QP + 32 * qp + 28, (unsigned)(qd > 6 ? qd - 6 : 0) | ((unsigned)(qd < 6 ? 6 - qd : 0) << 8));
   }
-  for (int k = tid; k < 192; k += nthreads) {
-    // entry of (table row m, pixel pair p, pixel e): shift | DC flag << 5 | three tile offsets relative to
-    // (block origin - one row - one column) << 8/16/24. P.t4 names a sample by its index j on the line
-    // E = [L3 L2 L1 L0 | corner | T0..T7] and says whether the pixel is E[j], the 3-tap or the 2-tap value there.
-    // Rows 0..8 = the modes, 9 = zero prediction (quirk Q4), 10 / 11 = modes 3 / 7 without a top-right block.
-    const int m = k >> 4, p = (k >> 1) & 7, e = k & 1;
-    const int x = 2 * (p & 1) + e, y = p >> 1;
-    const int mode = m < 10 ? m : (m == 10 ? 3 : 7), jmax = m < 10 ? 12 : 8;
-    unsigned v;
-    if (mode == 9) v = 31u;
-    else if (mode == 2) v = 31u | 32u;
-    else {
-      const int en = P.t4[mode * 16 + y * 4 + x], j = en & 31, sel = en >> 5;
-      const int ja = sel == 1 ? j - 1 : j, jb = sel == 2 ? j + 1 : j, jc = sel == 1 ? j + 1 : j;
-      const int a = min(max(ja, 0), jmax), bq = min(max(jb, 0), jmax), c = min(max(jc, 0), jmax);
-      const unsigned pa = (unsigned)(a <= 3 ? (4 - a) * TILE_STRIDE : a - 4);
-      const unsigned pb = (unsigned)(bq <= 3 ? (4 - bq) * TILE_STRIDE : bq - 4);
-      const unsigned pc = (unsigned)(c <= 3 ? (4 - c) * TILE_STRIDE : c - 4);
-      v = 2u | (pa << 8) | (pb << 16) | (pc << 24);
+  for (int k = tid; k < 128; k += nthreads) {
+    // entry of (pixel pair p, table row m). P.t4 names a sample by its index j on the line [L3 L2 L1 L0 | corner | T0..T7]
+    // (byte E_L3 + j of the block's edge array) and says whether the pixel is E[j], the 3-tap or the 2-tap value there: as
+    // four bytes whose sum + 2 >> 2 is the pixel -- (a, b, b, c), (a, a, b, b), (a, a, a, a). The bytes of both pixels of a
+    // pair lie inside one aligned 8-byte window of the edge array for every row (checked on the host: tests/test_abi.py).
+    const int p = k >> 4, m = k & 15;
+    const int y = p >> 1;
+    int by[2][4];
+    bool zero = false;
+    for (int e = 0; e < 2; e++) {
+      const int x = 2 * (p & 1) + e;
+      if (m == T4R_ZERO || m == T4R_DC) { zero = true; by[e][0] = by[e][1] = by[e][2] = by[e][3] = 0; }
+      else if (m == T4R_DC_TOP) { for (int q = 0; q < 4; q++) by[e][q] = E_T0 + q; }
+      else if (m == T4R_DC_LEFT) { for (int q = 0; q < 4; q++) by[e][q] = E_L3 + q; }
+      else if (m == T4R_H16) { by[e][0] = by[e][1] = by[e][2] = by[e][3] = E_T0 + y; }
+      else if (m == T4R_PRED16) { by[e][0] = by[e][1] = by[e][2] = by[e][3] = 4 * y + x; }
+      else {
+        const int mode = m < 9 ? m : (m == T4R_NOTR3 ? 3 : 7), jmax = m < 9 ? 12 : 8;
+        const int en = P.t4[mode * 16 + y * 4 + x], j = en & 31, sel = en >> 5;
+        const int ja = sel == 1 ? j - 1 : j, jb = sel == 2 ? j + 1 : j, jc = sel == 1 ? j + 1 : j;
+        by[e][0] = E_L3 + min(max(ja, 0), jmax);
+        by[e][1] = by[e][2] = E_L3 + min(max(jb, 0), jmax);
+        by[e][3] = E_L3 + min(max(jc, 0), jmax);
+      }
     }
-    wv::lds_st32(ldsBase + T_T4E + 96 * p + 8 * m + 4 * e, v);
+    int lo = 15;
+    for (int e = 0; e < 2; e++) for (int q = 0; q < 4; q++) lo = min(lo, by[e][q]);
+    const int off = zero ? 0 : lo & ~3;
+    unsigned sel[2];
+    for (int e = 0; e < 2; e++) {
+      sel[e] = 0;
+      for (int q = 0; q < 4; q++) sel[e] |= (zero ? (m == T4R_DC ? 0x0du : 0x0cu) : (unsigned)((by[e][q] - off) & 7)) << (8 * q);
+    }
+    wv::lds_st128(ldsBase + T_T4W + T4W_PAIR * p + 16 * m, u32x4{(unsigned)off, sel[0], sel[1], 0u});
   }
   if (hasI8) {
     for (int k = tid; k < 384; k += nthreads) wv::lds_st16(ldsBase + T_LS8 + 2 * k, P.ls8[k]);
@@ -1065,7 +1103,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
       if (lane == 63) wv::lds_st32(ts + S_CARRYM + 4 * g, rc);
       bottom = (isI4 || is8) ? ((unsigned)M[12] | ((unsigned)M[13] << 8) | ((unsigned)M[14] << 16) | ((unsigned)M[15] << 24)) : 0x02020202u;
 
-      // ---- the record: table rows of the chain
+      // ---- the record: table rows of the chain (T4R_*), 16 x the row = the byte offset of its entry
       unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, dcMask = 0;
       if (wv::any(isI4)) {
         int T[16];
@@ -1073,13 +1111,13 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
         for (int b = 0; b < 16; b++) T[b] = M[b];
         // modes 3 and 7 without a top-right block: T4..T7 := T3 (table rows 10 and 11). Inside the macroblock positions
         // (1,1) (3,1) (3,2) (1,3) (3,3) never have one; the top row has the neighbours' (B, B, B, C)
-        auto no_tr = [](int m) -> int { return (m & 3) == 3 ? 10 + (m >> 2) : m; };
+        auto no_tr = [](int m) -> int { return (m & 3) == 3 ? T4R_NOTR3 + (m >> 2) : m; };
         T[5] = no_tr(T[5]); T[7] = no_tr(T[7]); T[11] = no_tr(T[11]); T[13] = no_tr(T[13]); T[15] = no_tr(T[15]);
         if (!rowTop) { T[0] = no_tr(T[0]); T[1] = no_tr(T[1]); T[2] = no_tr(T[2]); }
         T[3] = (rowTop && !xLast) ? T[3] : no_tr(T[3]);
         if (!rowTop || x0 == 0) {
-          // quirk Q4 (picture edges only): a mode whose reference samples are missing leaves the zero-initialised
-          // prediction (table row 9)
+          // picture edges only. Quirk Q4: a mode whose reference samples are missing leaves the zero-initialised prediction
+          // (row T4R_ZERO); DC with one neighbour or none has rows of its own (none: the left column reads 128)
 #pragma unroll
           for (int b = 0; b < 16; b++) {
             const int bx = b & 3, by = b >> 2;
@@ -1087,30 +1125,42 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
             const bool topAv = by > 0 || rowTop, leftAv = bx > 0 || !xIs0;
             const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
             const int req = (int)((0x217771021ull >> (4 * M[b])) & 7ull);  // per mode: bit0 top, bit1 left, bit2 corner
-            if ((req & ~have) != 0) T[b] = 9;
+            if ((req & ~have) != 0) T[b] = T4R_ZERO;
+            if (M[b] == 2 && !(topAv && leftAv)) T[b] = topAv ? T4R_DC_TOP : T4R_DC_LEFT;
           }
         }
-        // x 8 (the table row's byte offset), in the order [block half][chain round]: round t = bx + 2 by; the first half
-        // is the block with the smaller by
+        // x 16, in the order [block half][chain round]: round t = bx + 2 by; the first half is the block with the smaller by
         auto pk = [](int a, int b2, int c, int e) -> unsigned {
-          return ((unsigned)a << 3) | ((unsigned)b2 << 11) | ((unsigned)c << 19) | ((unsigned)e << 27);
+          return ((unsigned)a << 4) | ((unsigned)b2 << 12) | ((unsigned)c << 20) | ((unsigned)e << 28);
         };
         w0 = pk(T[0], T[1], T[2], T[3]);            // rounds 0..3: (0,0) (1,0) (2,0) (3,0)
         w1 = pk(T[6], T[7], T[10], T[11]);          // rounds 4..7: (2,1) (3,1) (2,2) (3,2)
         w2 = pk(T[14], T[15], 0, 0);                // rounds 8, 9: (2,3) (3,3)
         w3 = pk(0, 0, T[4], T[5]);                  // second half, rounds 2, 3: (0,1) (1,1)
         w4 = pk(T[8], T[9], T[12], T[13]);          // ... rounds 4..7: (0,2) (1,2) (0,3) (1,3)
-        // rounds with a DC block: bytes equal to 16 (all bytes are < 128: no carry between the bytes of the sum)
-        auto dc4 = [](unsigned w) -> unsigned { return ~((w ^ 0x10101010u) + 0x7f7f7f7fu) & 0x80808080u; };
+        // rounds with a block whose value is the block's DC: bytes equal to 16 * T4R_DC (exact per byte: no carry between bytes)
+        auto dc4 = [](unsigned w) -> unsigned {
+          const unsigned v = w ^ (0x01010101u * (16u * T4R_DC));
+          return ~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u;
+        };
         auto gather = [](unsigned zz) -> unsigned {  // bits 7, 15, 23, 31 -> bits 0..3
           unsigned q = zz >> 7;
           q |= q >> 7;
           return (q | (q >> 14)) & 15u;
         };
-        dcMask = gather(dc4(w0) | dc4(w3)) | (gather(dc4(w1) | dc4(w4)) << 4) | (gather(dc4(w2)) << 8);
-        if (!isI4) w0 = w1 = w2 = w3 = w4 = dcMask = 0u;
+        dcMask = gather(dc4(w0) | (dc4(w3) & 0x80800000u)) | (gather(dc4(w1) | dc4(w4)) << 4) | (gather(dc4(w2) & 0x00008080u) << 8);
       }
-      if (HAS_I8 && is8) w0 = ((unsigned)M[0] << 3) | ((unsigned)M[2] << 11) | ((unsigned)M[8] << 19) | ((unsigned)M[10] << 27);
+      if (!isI4) {
+        // every other kind: one row for all sixteen blocks. Intra16x16 rides the block chain on edge arrays that band_back
+        // fills from the macroblock's own neighbours (vertical / horizontal: the top line / left column; DC and plane: the
+        // predicted pixels themselves); without the samples a mode needs, and for an unsupported record: zero prediction
+        const int m16 = (int)((word0 >> 8) & 3u);
+        int r16 = T4R_ZERO;
+        if (kind == 2) r16 = m16 == 0 ? (rowTop ? 0 : T4R_ZERO) : m16 == 1 ? (xIs0 ? T4R_ZERO : T4R_H16) : (m16 == 2 || (rowTop && !xIs0)) ? T4R_PRED16 : T4R_ZERO;
+        w0 = w1 = w2 = w3 = w4 = 0x10101010u * (unsigned)r16;
+        dcMask = 0u;
+      }
+      if (HAS_I8 && is8) w0 = ((unsigned)M[0] << 4) | ((unsigned)M[2] << 12) | ((unsigned)M[8] << 20) | ((unsigned)M[10] << 28);
       if (HAS_I8) {
         if (valid) {
           unsigned* rec = recF + (size_t)MREC_WORDS * mb;
@@ -1883,7 +1933,7 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
         u32x2 rrs[4];
 #pragma unroll
         for (int b8 = 0; b8 < 4; b8++) {
-          const int m8 = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
+          const int m8 = min((int)((modes4 >> (8 * b8 + 4)) & 0xfu), 8);
           te4s[b8] = wv::lds_u32(ldsBase + T_T8 + 64 * m8 + 8 * py + x0);
           rrs[b8] = wv::lds_u64(resBuf + RES_ROW * g + 32 * (4 * (2 * (b8 >> 1) + (py >> 2)) + 2 * (b8 & 1) + (x0 >> 2)) + 8 * (py & 3));
         }
@@ -1892,7 +1942,7 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
           const int bx = b8 & 1, by = b8 >> 1;
           const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA, tlAv = topAv && leftAv;
           const bool trAv = b8 == 0 ? mbB : b8 == 1 ? mbC : b8 == 2;
-          const int mode = min((int)((modes4 >> (8 * b8 + 3)) & 0x1fu), 8);
+          const int mode = min((int)((modes4 >> (8 * b8 + 4)) & 0xfu), 8);
           const int org8 = tile + TILE_STRIDE * (8 * by) + 8 + 16 * slot + 8 * bx;  // row y = -1, x = 0 of the block
           // raw edge samples k = i and k = i + 16 (top-right replaced by T7 when unavailable)
           auto eaddr = [&](int k) -> int {
@@ -1999,8 +2049,8 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 
     const int lane = lane0;  // (BACK has registers to spare: whatever depends on the lane alone is computed once, outside the loop)
     const int g = lane >> 4, i = lane & 15;
-    const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);  // lane-per-block: blkIdx i (z-order)
-    const int ch = (i >> 3) & 1, cp = i & 7;                                          // Intra4x4 chain: block half, pixel pair
+    const int ch = (i >> 3) & 1, cp = i & 7;        // block chain: block half, pixel pair
+    const int bxp = i & 3, part = i >> 2;           // edge arrays: block column, block row / which part of a top-row block's array
     const int r = r0 + g;
     const bool rowOk = g < nR;
     const bool mbB = r > 0;
@@ -2009,194 +2059,189 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
     const bool mbA = x > 0;
     const int slot = x & 1;
     const int tile = tile_of(ts, g, x);
+    const int eG = ts + S_EDGE + E_ROW * g;   // the row group's edge arrays: block (bx, by) at E_SLOT * (4 * by + bx)
     const unsigned info = wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g);
     const int kind = (int)(info & 3u), i16mode = (int)((info >> 8) & 3u);
     PH(0);  // wait for the record
 
-    // (the bottom luma lines of the band above are in row 0's ring: FRONT fetched them)
-    // top border of the luma tile: corner dword of x-1, 16 bytes of x, 8 bytes of x+1 (the top-right neighbour: its
-    // row above finished it in the previous step, or FRONT fetched it with this step's record)
-    // (an Intra8x8 macroblock's border is copied by BACK8, which predicts it)
-    if (i < 7 && !(HAS_I8 && kind == 1)) {
-      const int e = i == 0 ? x - 1 : i < 5 ? x : x + 1;
-      const int so = i == 0 ? 12 : i < 5 ? 4 * (i - 1) : 4 * (i - 5);
-      const unsigned v = wv::lds_u32(ringy(ts, g, e, par) + so);
-      wv::lds_st32(tile + 4 + 16 * slot + 4 * i, v);
+    // ================= edge arrays of the step's macroblocks ====================================================
+    // Everything a block's prediction reads sits in its 16-byte edge array (E_*). Inside a macroblock the arrays are filled
+    // where the pixels are written (the chain's scatter, below); here: what comes from outside the macroblock.
+    //   * Intra4x4: the top row's blocks (bx, 0) take T0..T3, T4..T7 and the corner from the line ring (lanes 4 * part + bx:
+    //     part 0, 1, 2); the left column's blocks got L3..L0 and their corners at the write-out of the step before.
+    //   * Intra16x16 rides the chain too: all sixteen blocks (lane i = block 4 * by + bx) take the macroblock's own top line
+    //     (vertical: table row 0) resp. left column (horizontal: T4R_H16) into T0..T3, or -- DC and plane, T4R_PRED16 -- their
+    //     sixteen predicted pixels.
+    EXP_REP(3)
+    {
+      const bool i4 = kind == 0, i16 = kind == 2;
+      const int de = i4 ? ((part == 1 && bxp == 3) ? 1 : (part == 2 && bxp == 0) ? -1 : 0) : 0;
+      const int so = i4 ? (part == 0 ? 4 * bxp : part == 1 ? (bxp < 3 ? 4 * bxp + 4 : 0) : (bxp > 0 ? 4 * bxp - 4 : 12)) : 4 * bxp;
+      const unsigned tw = wv::lds_u32(ringy(ts, g, x + de, par) + so);
+      const unsigned lw = wv::lds_u32(ts + S_LEFTY + 16 * g + 4 * part);
+      const int dst = i4 ? eG + E_SLOT * bxp + (part == 0 ? E_T0 : part == 1 ? E_T4 : E_CORNER) : eG + E_SLOT * i + E_T0;
+      if (valid && ((i4 && part < 2) || (i16 && i16mode < 2))) wv::lds_st32(dst, (i16 && i16mode == 1) ? lw : tw);
+      if (valid && i4 && part == 2) wv::lds_st8(dst, tw >> 24);
+      if (wv::any(valid && i16 && i16mode == 2)) {
+        // Intra16x16 DC (pred16x16.rs:291-361): one reduction over the row group of the available sums
+        int sm = ((part == 0 && mbB) ? (int)wv::sad4(tw) : 0) + ((bxp == 0 && mbA) ? (int)wv::sad4(lw) : 0);
+        sm += xor8(sm);
+        sm += xor4(sm, (i & 4) != 0);
+        sm += xor2(sm);
+        sm += xor1(sm);
+        const unsigned v = (unsigned)((mbA && mbB) ? (sm + 16) >> 5 : (mbA || mbB) ? (sm + 8) >> 4 : 128) * 0x01010101u;
+        if (valid && i16 && i16mode == 2) wv::lds_st128(eG + E_SLOT * i, u32x4{v, v, v, v});
+      }
+      if (!EXP_SKIP(3) && wv::any(valid && i16 && i16mode == 3 && mbA && mbB)) {
+        // Intra16x16 plane (8.3.3.4, pred16x16.rs:366-424). Every lane of the macroblock forms H, V from the whole top line and
+        // left column: H = sum (k + 1) (T[8 + k] - T[6 - k]), T[-1] = the corner, as four byte dot products
+        const u32x4 t = wv::lds_u128(ringy(ts, g, x, par)), l = wv::lds_u128(ts + S_LEFTY + 16 * g);
+        const unsigned c8 = 8u * wv::lds_u8(ringy(ts, g, x - 1, par) + 15);
+        const int hs = (int)wv::dot4(t.z, 0x04030201u, wv::dot4(t.w, 0x08070605u, 0u)) - (int)wv::dot4(t.y, 0x00010203u, wv::dot4(t.x, 0x04050607u, c8));
+        const int vs = (int)wv::dot4(l.z, 0x04030201u, wv::dot4(l.w, 0x08070605u, 0u)) - (int)wv::dot4(l.y, 0x00010203u, wv::dot4(l.x, 0x04050607u, c8));
+        const int a = 16 * (int)((l.w >> 24) + (t.w >> 24));
+        const int bq = (5 * hs + 32) >> 6, c = (5 * vs + 32) >> 6;
+        // pixel (x, y) of the macroblock: clip255((a + b (x - 7) + c (y - 7) + 16) >> 5); all terms fit 16 bits. This lane's block:
+        // (bxp, part)
+        const int base = a + bq * (4 * bxp - 7) + c * (4 * part - 7) + 16;
+        const unsigned b01 = ((unsigned)base & 0xffffu) | ((unsigned)(base + bq) << 16);
+        const unsigned step2 = ((unsigned)(2 * bq) & 0xffffu) | ((unsigned)(2 * bq) << 16);
+        const unsigned cc = ((unsigned)c & 0xffffu) | ((unsigned)c << 16);
+        unsigned q01 = b01, q23 = wv::pk_add(b01, step2), row[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          row[kk] = wv::perm(wv::sat_pk_u8(wv::pk_ashr5(q23)), wv::sat_pk_u8(wv::pk_ashr5(q01)), 0x05040100u);
+          q01 = wv::pk_add(q01, cc);
+          q23 = wv::pk_add(q23, cc);
+        }
+        if (valid && i16 && i16mode == 3 && mbA && mbB) wv::lds_st128(eG + E_SLOT * i, u32x4{row[0], row[1], row[2], row[3]});
+      }
+      // no macroblock to the left: the left column reads 128 (DC of a block with no neighbour at all: T4R_DC_LEFT; nothing
+      // else reads it there)
+      if (wv::any(valid && x == 0 && i4)) {
+        if (valid && x == 0 && i4) wv::lds_st8(eG + 4 * E_SLOT * part + E_L3 + 3 - bxp, 128u);
+      }
     }
     wv::wave_sync();
-    PH(1);  // top border
+    PH(1);  // edge arrays
+      PH(2);
+      PH(3);
+      const bool mine = valid && !(HAS_I8 && kind == 1);
+      const bool anyChain = !EXP_SKIP(4) && wv::any(mine);
 
-      // ================= luma, Intra16x16 (8.3.3, pred16x16.rs:79-425), lane = block (zbx, zby) ===================
-      EXP_REP(3)
-      if (!EXP_SKIP(3) && wv::any(valid && kind >= 2)) {
-        const unsigned tw = wv::lds_u32(tile + 8 + 16 * slot + 4 * zbx);   // row y = -1
-        const unsigned lw = wv::lds_u32(ts + S_LEFTY + 16 * g + 4 * zby);
-        unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
-        if (wv::any(valid && kind == 2 && i16mode == 2)) {
-          // DC: one reduction over the row group of the available sums
-          int sm = ((zby == 0 && mbB) ? (int)wv::sad4(tw) : 0) + ((zbx == 0 && mbA) ? (int)wv::sad4(lw) : 0);
-          sm += xor8(sm);
-          sm += xor4(sm, (i & 4) != 0);
-          sm += xor2(sm);
-          sm += xor1(sm);
-          const int v = (mbA && mbB) ? (sm + 16) >> 5 : (mbA || mbB) ? (sm + 8) >> 4 : 128;
-          if (i16mode == 2) src = (unsigned)v * 0x01010101u;
-        }
-        if (i16mode == 0) {
-          src = mbB ? tw : 0u;
-          selA = 0x0c010c00u;
-          selB = 0x0c030c02u;
-          inc = 0;
-        } else if (i16mode == 1) {
-          if (!mbA) src = 0;
-        } else if (i16mode == 3) {
-          src = 0;
-        }
-        unsigned p01[4], p23[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          p01[k] = wv::perm(src, src, selA + inc * k);
-          p23[k] = wv::perm(src, src, selB + inc * k);
-        }
-        if (wv::any(valid && kind == 2 && i16mode == 3)) {
-          // plane (:366-424): lanes 0..7 of the row group: horizontal terms, 8..15: vertical terms.
-          // (its lane roles from an opaque lane id: they are then computed here, in the steps that have a plane macroblock,
-          // instead of living in registers for the whole kernel)
-          const int lane = wv::opaque(lane0);
-          const int g = lane >> 4, i = lane & 15;
-          const int zbx = ((i >> 1) & 2) | (i & 1), zby = ((i >> 2) & 2) | ((i >> 1) & 1);
-          const int k = i & 7;
-          const int tr0 = tile + 8 + 16 * slot, lf = ts + S_LEFTY + 16 * g;
-          const int corner = (int)wv::lds_u8(tr0 - 1);
-          const int ha = (int)wv::lds_u8(tr0 + 8 + k), hb = k == 7 ? corner : (int)wv::lds_u8(tr0 + 6 - k);
-          const int va = (int)wv::lds_u8(lf + 8 + k), vb = k == 7 ? corner : (int)wv::lds_u8(lf + 6 - k);
-          int term = (k + 1) * (i < 8 ? ha - hb : va - vb);
-          term += xor1(term);
-          term += xor2(term);
-          term += xor4(term, (i & 4) != 0);  // lanes 0..7: H, lanes 8..15: V
-          const int hs = wv::bperm(term, lane & 48), vs = wv::bperm(term, (lane & 48) + 8);
-          if (kind == 2 && i16mode == 3 && mbA && mbB) {
-            const int a = 16 * ((int)wv::lds_u8(lf + 15) + (int)wv::lds_u8(tr0 + 15));
-            const int bq = (5 * hs + 32) >> 6, c = (5 * vs + 32) >> 6;
-            const int base = a + bq * (4 * zbx - 7) + c * (4 * zby - 7) + 16;
-            const unsigned b01 = ((unsigned)base & 0xffffu) | ((unsigned)(base + bq) << 16);
-            const unsigned step2 = ((unsigned)(2 * bq) & 0xffffu) | ((unsigned)(2 * bq) << 16);
-            const unsigned cc = ((unsigned)c & 0xffffu) | ((unsigned)c << 16);
-            unsigned q01 = b01, q23 = wv::pk_add(b01, step2);
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-              const unsigned u01 = wv::sat_pk_u8(wv::pk_ashr5(q01)), u23 = wv::sat_pk_u8(wv::pk_ashr5(q23));
-              p01[kk] = wv::perm(0u, u01, 0x0c010c00u);
-              p23[kk] = wv::perm(0u, u23, 0x0c010c00u);
-              q01 = wv::pk_add(q01, cc);
-              q23 = wv::pk_add(q23, cc);
-            }
-          }
-        }
-        if (kind >= 2) {
-          if (kind == 3) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) p01[k] = p23[k] = 0;
-          }
-          const int rsrc = resBuf + RES_ROW * g + 32 * (4 * zby + zbx);
-          const u32x4 ra = wv::lds_u128(rsrc), rb = wv::lds_u128(rsrc + 16);
-          const unsigned rA[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-          const int dst = tile + TILE_STRIDE * (4 * zby + 1) + 8 + 16 * slot + 4 * zbx;
-#pragma unroll
-          for (int k = 0; k < 4; k++) wv::lds_st32(dst + TILE_STRIDE * k, recon_row(p01[k], p23[k], rA[2 * k], rA[2 * k + 1]));
-        }
-      }
-
-      wv::wave_sync();
-      PH(2);  // Intra16x16
-
-      PH(3);  // (nothing left here: the publication of the progress word went with the tagged hand-off records)
-      const bool anyI4 = !EXP_SKIP(4) && wv::any(valid && kind == 0);
-
-      // ================= luma, Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) =======================================
+      // ================= the block chain: Intra4x4 pixels (8.3.1.2, pred4x4.rs:10-360) and all of Intra16x16 (8.3.3) ======
       // lane = (row g, block half ch, pixel pair cp). Rounds with two blocks per macroblock (2..7): pixels
       // (2 * (cp & 1) + {0, 1}, cp >> 1) of block (bx0, by0) for ch = 0, of block (bx0 - 2, by0 + 1) for ch = 1. Rounds with
       // one block (0, 1, 8, 9): all sixteen lanes work on it, one pixel each: (2 * (cp & 1) + ch, cp >> 1).
+      // A pixel is (sum of four bytes of the block's edge array + 2) >> 2: the table entry of (row, pixel pair) names an aligned
+      // 8-byte window of the array and, per pixel, a byte selector on it (v_perm_b32), e.g. (a, b, b, c) for a three-tap value.
+      // An Intra4x4 block's pixels go to the tile and, where they are some block's neighbours, into that block's array:
+      // bottom row -> T0..T3 of the block below and T4..T7 of the block below left, right column -> L3..L0 of the block to
+      // the right, pixel (3, 3) -> the corner of the block below right. A lane that holds none of these writes to the dump
+      // bytes of its own block's array; destinations outside the macroblock are the spare block row 4 or left out per round.
       EXP_REP(4)
-      if (anyI4) {
-        const bool mine = valid && kind == 0;
-        const int px = 2 * (cp & 1), py = cp >> 1;
+      if (anyChain) {
+        const bool i4 = kind == 0;
+        const int px = 2 * (cp & 1), py = cp >> 1, xq = px + ch;
         const int seqA = ts + S_MSEQ + 96 * buf + 24 * g + 12 * ch;
-        // Everything a round addresses is a per-lane base (computed once per step) plus a constant of the round, which
-        // the LDS instructions carry as their immediate offset: the second block of a two-block round is always
-        // (bx - 2, by + 1) of the first, so its lanes' bases differ from the first block's by a constant.
+        // Everything a round addresses is a per-lane base plus a constant of the round, which the LDS instructions carry as
+        // their immediate offset: the second block of a two-block round is always (bx - 2, by + 1) of the first.
         const int orgS = tile + 8 + 16 * slot - 1;                  // (block origin - one row - one column) of block (0, 0)
         const int orgB = orgS + (ch ? 4 * TILE_STRIDE - 8 : 0);     // ... of block (0, 0) / (-2, 1)
         const int stB = orgB + TILE_STRIDE * (py + 1) + 1 + px, stS = orgS + TILE_STRIDE * (py + 1) + 1 + px + ch;
         const int resS = resBuf + RES_ROW * g + 4 * cp + 2 * ch;        // residuals [4 * by + bx][y][x]: this lane's one pixel
         const int resB = resBuf + RES_ROW * g + 4 * cp + (ch ? 64 : 0); // ... this lane's pixel pair
-        const int entB = ldsBase + T_T4E + 96 * cp, entS = entB + 4 * ch;
-        const bool nchOrA = ch == 0 || mbA;
-        // the table rows of all ten steps (they do not depend on pixels): this lane's block half, and the first half's
-        // for the one-block rounds; then entry and residual one step ahead
+        const int eB = eG + (ch ? 2 * E_SLOT : 0);                   // edge array of block (0, 0) / (-2, 1)
+        const int entB = ldsBase + T_T4W + T4W_PAIR * cp, entS = entB + 4 + 4 * ch;   // table entries of the pair; the lane's one pixel's selector
+        // scatter destinations (+ the round's E_SLOT * (4 * by0 + bx0))
+        // (a lane with nothing to scatter writes to the dump bytes of a slot of its own, E_SLOT * cp further: eight lanes on one
+        // dword would be an eight-way bank conflict in every store)
+#ifndef DRYV_BAND_SCATTER_MASKED
+#define DRYV_BAND_SCATTER_MASKED 0
+#endif
+#ifndef DRYV_BAND_DUMP_SPREAD
+#define DRYV_BAND_DUMP_SPREAD 0
+#endif
+        const int dumpB = eB + (DRYV_BAND_DUMP_SPREAD ? E_SLOT * cp : 0) + E_DUMP, dumpS = eG + (DRYV_BAND_DUMP_SPREAD ? E_SLOT * cp : 0) + E_DUMP;
+        const int aW1 = py == 3 ? eB + 4 * E_SLOT + E_T0 + px : dumpB;
+        const int aW2 = py == 3 ? eB + 3 * E_SLOT + E_T4 + px : dumpB, aW2c0 = ch ? dumpB : aW2;
+        const int aW3 = px == 2 ? eB + E_SLOT + E_L3 + 3 - py : dumpB, aW3c1 = ch ? aW3 : dumpB;
+        const int aW4 = cp == 7 ? eB + 5 * E_SLOT + E_CORNER : dumpB, aW4c1 = ch ? aW4 : dumpB;
+        const int aS1 = py == 3 ? eG + 4 * E_SLOT + E_T0 + xq : dumpS, aS2 = py == 3 ? eG + 3 * E_SLOT + E_T4 + xq : dumpS;
+        const int aS3 = xq == 3 ? eG + E_SLOT + E_L3 + 3 - py : dumpS, aS4 = (xq == 3 && py == 3) ? eG + 5 * E_SLOT + E_CORNER : dumpS;
+        // the table rows of all ten rounds (they do not depend on pixels): this lane's block half, and the first half's
+        // for the one-block rounds; then entry and residual one round ahead
         const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
         const unsigned sS0 = wv::lds_u32(seqA - 12 * ch), sS2 = wv::lds_u32(seqA - 12 * ch + 8);
-        u32x2 en = u32x2{wv::lds_u32(entS + (int)(sS0 & 0xffu)), 0u};
+        u32x4 en = u32x4{wv::lds_u32(entB + (int)(sS0 & 0xffu)), wv::lds_u32(entS + (int)(sS0 & 0xffu)), 0u, 0u};
         unsigned rr = (unsigned)wv::lds_i16(resS);
         const unsigned dcRounds = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 28));
+        constexpr unsigned SEL_DC = 0x0d0d0d0du;   // the selector of the row whose value is the block's DC
 #define I4_BODY(T, DC)                                                                                           \
         {                                                                                                         \
-          /* (the DC samples first: the two bodies then share no leading code the compiler could hoist above the */ \
-          /* branch, which would put these loads behind the wait for the others: a second LDS round trip) */     \
-          unsigned top = 0;                                                                                       \
-          int l0 = 0, l1 = 0, l2 = 0, l3 = 0;                                                                     \
-          if (DC) {                                                                                               \
-            const int orgX = two ? orgB : orgS;                                                                   \
-            top = wv::lds_u32(orgX + offT + 1);                                                                   \
-            l0 = (int)wv::lds_u8(orgX + offT + TILE_STRIDE), l1 = (int)wv::lds_u8(orgX + offT + 2 * TILE_STRIDE); \
-            l2 = (int)wv::lds_u8(orgX + offT + 3 * TILE_STRIDE), l3 = (int)wv::lds_u8(orgX + offT + 4 * TILE_STRIDE); \
-          }                                                                                                       \
-          u32x2 enN = en;                                                                                         \
+          const unsigned lo = wv::lds_u32(q + offE), hi = wv::lds_u32(q + offE + 4);                              \
+          u32x4 ee = u32x4{0u, 0u, 0u, 0u};                                                                       \
+          if (DC) ee = wv::lds_u128((two ? eB : eG) + offE);                                                      \
+          u32x4 enN = en;                                                                                         \
           unsigned rrN;                                                                                           \
           if (twoN) {                                                                                             \
             const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                  \
-            enN = wv::lds_u64(entB + (int)mN);                                                                    \
+            enN = wv::lds_u128(entB + (int)mN);                                                                   \
             rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                                       \
           } else {                                                                                                \
             const unsigned mN = ((TN < 4 ? sS0 : sS2) >> (8 * (TN & 3))) & 0xffu;                                 \
-            enN.x = wv::lds_u32(entS + (int)mN);                                                                  \
+            enN.x = wv::lds_u32(entB + (int)mN);                                                                  \
+            enN.y = wv::lds_u32(entS + (int)mN);                                                                  \
             rrN = (unsigned)wv::lds_i16(resS + 32 * (4 * byN + bxN));                                             \
           }                                                                                                       \
+          unsigned dcv = 0;                                                                                       \
+          if (DC) {                                                                                               \
+            /* DC (pred4x4.rs:116-167) with both neighbours: (L0 + .. + L3 + T0 + .. + T3 + 4) >> 3 of the block's own array */ \
+            dcv = wv::dot4(ee.x, 0x01000000u, wv::dot4(ee.y, 0x00010101u, wv::dot4(ee.z, 0x01010101u, 4u))) >> 3; \
+          }                                                                                                       \
           if (two) {                                                                                              \
-            const int a0 = (int)wv::lds_u8(q0 + offT), a1 = (int)wv::lds_u8(q1 + offT), a2 = (int)wv::lds_u8(q2 + offT); \
-            const int b0 = (int)wv::lds_u8(q3 + offT), b1 = (int)wv::lds_u8(q4 + offT);                           \
-            const int b2 = wv::opaque((int)wv::lds_u8(q5 + offT));                                                \
-            int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                     \
-            int pb = (int)((unsigned)(b0 + 2 * b1 + b2 + 2) >> (en.y & 31u));                                     \
-            if (DC) {                                                                                             \
-              /* DC (pred4x4.rs:116-167): its samples are fetched with the others (one LDS round trip, no branch). */ \
-              /* Availability of the round's blocks: (bx0, by0) for ch = 0, (bx0 - 2, by0 + 1) for ch = 1 */      \
-              const bool topAv = by0 > 0 ? true : (ch != 0 || mbB);                                               \
-              const bool leftAv = bx0 == 2 ? nchOrA : true;                                                       \
-              const int sm = (topAv ? (int)wv::sad4(top) : 0) + (leftAv ? l0 + l1 + l2 + l3 : 0);                 \
-              /* one sum alone counts twice: (sm + 2) >> 2 == (2 * sm + 4) >> 3 */                                \
-              int dc = ((sm << ((topAv && leftAv) ? 0 : 1)) + 4) >> 3;                                            \
-              if (!topAv && !leftAv) dc = 128;                                                                    \
-              /* (opaque: otherwise the compiler, seeing that only 16 bits of dc are used, narrows the whole sum */ \
-              /* to 16-bit arithmetic and masks every loaded byte) */                                             \
-              dc = wv::opaque(dc);                                                                                \
-              if (en.x & 32u) pa = pb = dc;                                                                       \
+            const unsigned pa = wv::perm(hi, lo, en.y), pb = wv::perm(hi, lo, en.z);                              \
+            unsigned pr = wv::pk_lshr2(wv::sum4_hi(pb, wv::sum4(pa, 0x00020002u)));                               \
+            if (DC) pr = en.y == SEL_DC ? dcv * 0x10001u : pr;                                                    \
+            const unsigned o = wv::sat_pk_u8(wv::pk_add_sat(pr, rr));                                             \
+            if (mine) {                                                                                           \
+              wv::lds_st16(stB + offT, o);                                                                        \
+              if (i4) {                                                                                           \
+                const unsigned o8 = o >> 8;                                                                       \
+                if (DRYV_BAND_SCATTER_MASKED) {                                                                   \
+                  if (py == 3) wv::lds_st16(aW1 + offE, o);                                                       \
+                  if (py == 3 && (((T) & 1) || ch == 0)) wv::lds_st16(aW2 + offE, o);                             \
+                  if (px == 2 && (!((T) & 1) || ch == 1)) wv::lds_st8(aW3 + offE, o8);                            \
+                  if (cp == 7 && (!((T) & 1) || ch == 1)) wv::lds_st8(aW4 + offE, o8);                            \
+                } else {                                                                                          \
+                wv::lds_st16(aW1 + offE, o);                                                                      \
+                wv::lds_st16((((T) & 1) ? aW2 : aW2c0) + offE, o);                                                \
+                wv::lds_st8((((T) & 1) ? aW3c1 : aW3) + offE, o8);                                                \
+                wv::lds_st8((((T) & 1) ? aW4c1 : aW4) + offE, o8);                                                \
+                }                                                                                                 \
+              }                                                                                                   \
             }                                                                                                     \
-            const unsigned o = wv::sat_pk_u8(wv::pk_add_sat((unsigned)pa | ((unsigned)pb << 16), rr));            \
-            if (mine) wv::lds_st16(stB + offT, o);                                                                \
           } else {                                                                                                \
-            const int a0 = (int)wv::lds_u8(q0 + offT), a1 = (int)wv::lds_u8(q1 + offT);                           \
-            const int a2 = wv::opaque((int)wv::lds_u8(q2 + offT));                                                \
-            int pa = (int)((unsigned)(a0 + 2 * a1 + a2 + 2) >> (en.x & 31u));                                     \
-            if (DC) {                                                                                             \
-              const bool topAv = by0 > 0 ? true : mbB, leftAv = bx0 > 0 ? true : mbA;                             \
-              const int sm = (topAv ? (int)wv::sad4(top) : 0) + (leftAv ? l0 + l1 + l2 + l3 : 0);                 \
-              int dc = ((sm << ((topAv && leftAv) ? 0 : 1)) + 4) >> 3;                                            \
-              if (!topAv && !leftAv) dc = 128;                                                                    \
-              if (en.x & 32u) pa = dc;                                                                            \
+            const unsigned pq = wv::perm(hi, lo, en.y);                                                           \
+            int pv = (int)(wv::sum4(pq, 2u) >> 2);                                                                \
+            if (DC) pv = en.y == SEL_DC ? (int)dcv : pv;                                                          \
+            const int o = wv::med3(pv + (int)rr, 0, 255);                                                         \
+            if (mine) {                                                                                           \
+              wv::lds_st8(stS + offT, (unsigned)o);                                                               \
+              if (i4) {                                                                                           \
+                if (DRYV_BAND_SCATTER_MASKED) {                                                                   \
+                  if ((T) < 2 && py == 3) wv::lds_st8(aS1 + offE, (unsigned)o);                                   \
+                  if ((T) == 1 && py == 3) wv::lds_st8(aS2 + offE, (unsigned)o);                                  \
+                  if ((T) != 9 && xq == 3) wv::lds_st8(aS3 + offE, (unsigned)o);                                  \
+                  if ((T) < 2 && xq == 3 && py == 3) wv::lds_st8(aS4 + offE, (unsigned)o);                        \
+                } else {                                                                                          \
+                if ((T) < 2) wv::lds_st8(aS1 + offE, (unsigned)o);                                                \
+                if ((T) == 1) wv::lds_st8(aS2 + offE, (unsigned)o);                                               \
+                if ((T) != 9) wv::lds_st8(aS3 + offE, (unsigned)o);                                               \
+                if ((T) < 2) wv::lds_st8(aS4 + offE, (unsigned)o);                                                \
+                }                                                                                                 \
+              }                                                                                                   \
             }                                                                                                     \
-            const int o = wv::med3(pa + (int)rr, 0, 255);                                                         \
-            if (mine) wv::lds_st8(stS + offT, (unsigned)o);                                                       \
           }                                                                                                       \
           en = enN;                                                                                               \
           rr = rrN;                                                                                               \
@@ -2209,17 +2254,11 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           constexpr int byN = stepByLo(TN), bxN = TN - 2 * byN;                                                   \
           constexpr bool twoN = byN + 1 <= stepByHi(TN);                                                          \
           constexpr int offT = TILE_STRIDE * 4 * by0 + 4 * bx0;                                                   \
-          /* sample addresses: base + table offset behind an optimisation barrier, so that the round's constant */ \
+          constexpr int offE = E_SLOT * (4 * by0 + bx0);                                                          \
+          /* the window's address: base + table offset behind an optimisation barrier, so that the round's constant */ \
           /* rides in the loads' immediate offset instead of being added to the base once per round */            \
-          const int orgQ = two ? orgB : orgS;                                                                     \
-          const int q0 = wv::opaque(orgQ + (int)((en.x >> 8) & 0xffu)), q1 = wv::opaque(orgQ + (int)((en.x >> 16) & 0xffu)); \
-          const int q2 = wv::opaque(orgQ + (int)(en.x >> 24));                                                    \
-          int q3 = 0, q4 = 0, q5 = 0;                                                                             \
-          if (two) {                                                                                              \
-            q3 = wv::opaque(orgB + (int)((en.y >> 8) & 0xffu)), q4 = wv::opaque(orgB + (int)((en.y >> 16) & 0xffu)); \
-            q5 = wv::opaque(orgB + (int)(en.y >> 24));                                                            \
-          }                                                                                                       \
-          /* (wave-uniform: FRONT marked the rounds in which some block of the step is predicted DC) */           \
+          const int q = wv::opaque((two ? eB : eG) + (int)en.x);                                                  \
+          /* (wave-uniform: the mode pre-pass marked the rounds in which some block of the step takes its own DC) */ \
           if (dcRounds & (1u << (T))) I4_BODY(T, true) else I4_BODY(T, false)                                     \
           wv::wave_sync();                                                                                        \
         }
@@ -2228,7 +2267,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
 #undef I4_BODY
       }
 
-      PH(4);  // Intra4x4 chain
+      PH(4);  // block chain
       // (builds with the 8x8 transform: the step's Intra8x8 macroblocks are BACK8's, which worked next to the chain)
       // (at least: BACK8 may already be through a next step that has none)
       if (HAS_I8) team_wait_ge(ts + S_F8 + F8_DONE, gstep + 1);
@@ -2253,11 +2292,15 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
             wv::st_sc1_64((unsigned long long*)handMy + ((HAND_WORDS / 2) * x + i), (unsigned long long)v | ((unsigned long long)A.gen << 32));
         }
       }
-      // left neighbour copy: luma column 15 (also the tile's x = -1 border when the next macroblock is slot 0)
+      // left neighbour copy: luma column 15 -> the left column (Intra16x16), L3..L0 and the corners of the next macroblock's
+      // blocks (0, by) (lane i = pixel row: block row i >> 2), and, for BACK8, the tile's x = -1 border when the next macroblock is
+      // slot 0
       {
         const unsigned v = wv::lds_u8(tile + TILE_STRIDE * (i + 1) + 8 + 16 * slot + 15);
         wv::lds_st8(ts + S_LEFTY + 16 * g + i, v);
-        if (slot == 1) wv::lds_st8(tile_of(ts, g, x + 1) + TILE_STRIDE * (i + 1) + 7, v);
+        wv::lds_st8(eG + 4 * E_SLOT * part + E_L3 + 3 - bxp, v);
+        wv::lds_st8(eG + ((bxp == 3 && part < 3) ? 4 * E_SLOT * (part + 1) + E_CORNER : E_DUMP), v);
+        if (HAS_I8 && slot == 1) wv::lds_st8(tile_of(ts, g, x + 1) + TILE_STRIDE * (i + 1) + 7, v);
       }
       wv::wave_sync();
       // flush the staged rows: every NSY-th macroblock, or at the end of a row: 16 * NSY contiguous bytes per pixel row.

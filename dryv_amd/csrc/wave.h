@@ -66,6 +66,11 @@ WV void lds_st128(int a, u32x4 v) { *WV_LDS(u32x4, a) = v; }
 // ---- VALU helpers -------------------------------------------------------------------------------------
 WV unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 WV unsigned sad4(unsigned w) { return __builtin_amdgcn_sad_u8(w, 0u, 0u); }
+// sum of the four bytes of w, plus acc (v_sad_u8 against 0); the same sum in bits 31:16, plus acc (v_sad_hi_u8)
+WV unsigned sum4(unsigned w, unsigned acc) { return __builtin_amdgcn_sad_u8(w, 0u, acc); }
+WV unsigned sum4_hi(unsigned w, unsigned acc) { return __builtin_amdgcn_sad_hi_u8(w, 0u, acc); }
+// a.b0 * b.b0 + ... + a.b3 * b.b3 + acc on unsigned bytes (v_dot4_u32_u8)
+WV unsigned dot4(unsigned a, unsigned b, unsigned acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
 WV int med3(int a, int lo, int hi) { return min(max(a, lo), hi); }
 // the same as one instruction for bounds the compiler cannot order (lo <= hi is the caller's business)
 WV int clamp3(int a, int lo, int hi) {
@@ -85,6 +90,11 @@ WV unsigned pk_ashr5(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(_
 WV unsigned pk_ashr1(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 1)); }
 WV unsigned pk_ashr6(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 6)); }
 WV unsigned pk_ashr2(unsigned a) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) >> 2)); }
+// both unsigned halves >> 2 (v_pk_lshrrev_b16)
+WV unsigned pk_lshr2(unsigned a) {
+  typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, (u16x2_)(__builtin_bit_cast(u16x2_, a) >> 2));
+}
 // per-half shift left by the low four bits of the matching half of sh (v_pk_lshlrev_b16)
 WV unsigned pk_shl(unsigned a, unsigned sh) {
   return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) << (__builtin_bit_cast(s16x2, sh) & (s16x2)15)));

@@ -127,6 +127,13 @@ WV unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
   return r;
 }
 WV unsigned sad4(unsigned w) { return (w & 0xff) + ((w >> 8) & 0xff) + ((w >> 16) & 0xff) + (w >> 24); }
+WV unsigned sum4(unsigned w, unsigned acc) { return sad4(w) + acc; }
+WV unsigned sum4_hi(unsigned w, unsigned acc) { return (sad4(w) << 16) + acc; }
+WV unsigned dot4(unsigned a, unsigned b, unsigned acc) {
+  for (int k = 0; k < 4; k++) acc += ((a >> (8 * k)) & 0xff) * ((b >> (8 * k)) & 0xff);
+  return acc;
+}
+WV unsigned pk_lshr2(unsigned a) { return ((a & 0xffff) >> 2) | ((a >> 18) << 16); }
 WV int med3(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
 WV int clamp3(int a, int lo, int hi) { return med3(a, lo, hi); }
 WV int emu_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
