@@ -2141,6 +2141,10 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       // bytes of its own block's array; destinations outside the macroblock are the spare block row 4 or left out per round.
       EXP_REP(4)
       if (anyChain) {
+      // (the whole chain under ONE lane mask: a macroblock's lanes take part in all ten rounds or in none, and a mask set and
+      // restored around every store of every round is a dozen scalar instructions per round on the wave that paces the band.
+      // In the emulator every lane walks through the rounds' barriers: the stores keep their predicate.)
+      WV_LANES_IF(mine) {
         const bool i4 = kind == 0;
         const int px = 2 * (cp & 1), py = cp >> 1, xq = px + ch;
         const int seqA = ts + S_MSEQ + 96 * buf + 24 * g + 12 * ch;
@@ -2153,22 +2157,16 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         const int resB = resBuf + RES_ROW * g + 4 * cp + (ch ? 64 : 0); // ... this lane's pixel pair
         const int eB = eG + (ch ? 2 * E_SLOT : 0);                   // edge array of block (0, 0) / (-2, 1)
         const int entB = ldsBase + T_T4W + T4W_PAIR * cp, entS = entB + 4 + 4 * ch;   // table entries of the pair; the lane's one pixel's selector
-        // scatter destinations (+ the round's E_SLOT * (4 * by0 + bx0))
-        // (a lane with nothing to scatter writes to the dump bytes of a slot of its own, E_SLOT * cp further: eight lanes on one
-        // dword would be an eight-way bank conflict in every store)
-#ifndef DRYV_BAND_SCATTER_MASKED
-#define DRYV_BAND_SCATTER_MASKED 0
-#endif
-#ifndef DRYV_BAND_DUMP_SPREAD
-#define DRYV_BAND_DUMP_SPREAD 0
-#endif
-        const int dumpB = eB + (DRYV_BAND_DUMP_SPREAD ? E_SLOT * cp : 0) + E_DUMP, dumpS = eG + (DRYV_BAND_DUMP_SPREAD ? E_SLOT * cp : 0) + E_DUMP;
-        const int aW1 = py == 3 ? eB + 4 * E_SLOT + E_T0 + px : dumpB;
-        const int aW2 = py == 3 ? eB + 3 * E_SLOT + E_T4 + px : dumpB, aW2c0 = ch ? dumpB : aW2;
-        const int aW3 = px == 2 ? eB + E_SLOT + E_L3 + 3 - py : dumpB, aW3c1 = ch ? aW3 : dumpB;
-        const int aW4 = cp == 7 ? eB + 5 * E_SLOT + E_CORNER : dumpB, aW4c1 = ch ? aW4 : dumpB;
-        const int aS1 = py == 3 ? eG + 4 * E_SLOT + E_T0 + xq : dumpS, aS2 = py == 3 ? eG + 3 * E_SLOT + E_T4 + xq : dumpS;
-        const int aS3 = xq == 3 ? eG + E_SLOT + E_L3 + 3 - py : dumpS, aS4 = (xq == 3 && py == 3) ? eG + 5 * E_SLOT + E_CORNER : dumpS;
+        // scatter destinations (+ the round's E_SLOT * (4 * by0 + bx0)). A lane with nothing to scatter -- by its pixels, or
+        // because its macroblock is not Intra4x4 (an Intra16x16 block's array is its own macroblock's, not its neighbours') --
+        // writes to the dump bytes of its block's array.
+        const int dumpB = eB + E_DUMP, dumpS = eG + E_DUMP;
+        const int aW1 = (i4 && py == 3) ? eB + 4 * E_SLOT + E_T0 + px : dumpB;
+        const int aW2 = (i4 && py == 3) ? eB + 3 * E_SLOT + E_T4 + px : dumpB, aW2c0 = ch ? dumpB : aW2;
+        const int aW3 = (i4 && px == 2) ? eB + E_SLOT + E_L3 + 3 - py : dumpB, aW3c1 = ch ? aW3 : dumpB;
+        const int aW4 = (i4 && cp == 7) ? eB + 5 * E_SLOT + E_CORNER : dumpB, aW4c1 = ch ? aW4 : dumpB;
+        const int aS1 = (i4 && py == 3) ? eG + 4 * E_SLOT + E_T0 + xq : dumpS, aS2 = (i4 && py == 3) ? eG + 3 * E_SLOT + E_T4 + xq : dumpS;
+        const int aS3 = (i4 && xq == 3) ? eG + E_SLOT + E_L3 + 3 - py : dumpS, aS4 = (i4 && xq == 3 && py == 3) ? eG + 5 * E_SLOT + E_CORNER : dumpS;
         // the table rows of all ten rounds (they do not depend on pixels): this lane's block half, and the first half's
         // for the one-block rounds; then entry and residual one round ahead
         const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
@@ -2205,21 +2203,12 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
             if (DC) pr = en.y == SEL_DC ? dcv * 0x10001u : pr;                                                    \
             const unsigned o = wv::sat_pk_u8(wv::pk_add_sat(pr, rr));                                             \
             if (mine) {                                                                                           \
+              const unsigned o8 = o >> 8;                                                                         \
               wv::lds_st16(stB + offT, o);                                                                        \
-              if (i4) {                                                                                           \
-                const unsigned o8 = o >> 8;                                                                       \
-                if (DRYV_BAND_SCATTER_MASKED) {                                                                   \
-                  if (py == 3) wv::lds_st16(aW1 + offE, o);                                                       \
-                  if (py == 3 && (((T) & 1) || ch == 0)) wv::lds_st16(aW2 + offE, o);                             \
-                  if (px == 2 && (!((T) & 1) || ch == 1)) wv::lds_st8(aW3 + offE, o8);                            \
-                  if (cp == 7 && (!((T) & 1) || ch == 1)) wv::lds_st8(aW4 + offE, o8);                            \
-                } else {                                                                                          \
-                wv::lds_st16(aW1 + offE, o);                                                                      \
-                wv::lds_st16((((T) & 1) ? aW2 : aW2c0) + offE, o);                                                \
-                wv::lds_st8((((T) & 1) ? aW3c1 : aW3) + offE, o8);                                                \
-                wv::lds_st8((((T) & 1) ? aW4c1 : aW4) + offE, o8);                                                \
-                }                                                                                                 \
-              }                                                                                                   \
+              wv::lds_st16(aW1 + offE, o);                                                                        \
+              wv::lds_st16((((T) & 1) ? aW2 : aW2c0) + offE, o);                                                  \
+              wv::lds_st8((((T) & 1) ? aW3c1 : aW3) + offE, o8);                                                  \
+              wv::lds_st8((((T) & 1) ? aW4c1 : aW4) + offE, o8);                                                  \
             }                                                                                                     \
           } else {                                                                                                \
             const unsigned pq = wv::perm(hi, lo, en.y);                                                           \
@@ -2228,19 +2217,10 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
             const int o = wv::med3(pv + (int)rr, 0, 255);                                                         \
             if (mine) {                                                                                           \
               wv::lds_st8(stS + offT, (unsigned)o);                                                               \
-              if (i4) {                                                                                           \
-                if (DRYV_BAND_SCATTER_MASKED) {                                                                   \
-                  if ((T) < 2 && py == 3) wv::lds_st8(aS1 + offE, (unsigned)o);                                   \
-                  if ((T) == 1 && py == 3) wv::lds_st8(aS2 + offE, (unsigned)o);                                  \
-                  if ((T) != 9 && xq == 3) wv::lds_st8(aS3 + offE, (unsigned)o);                                  \
-                  if ((T) < 2 && xq == 3 && py == 3) wv::lds_st8(aS4 + offE, (unsigned)o);                        \
-                } else {                                                                                          \
-                if ((T) < 2) wv::lds_st8(aS1 + offE, (unsigned)o);                                                \
-                if ((T) == 1) wv::lds_st8(aS2 + offE, (unsigned)o);                                               \
-                if ((T) != 9) wv::lds_st8(aS3 + offE, (unsigned)o);                                               \
-                if ((T) < 2) wv::lds_st8(aS4 + offE, (unsigned)o);                                                \
-                }                                                                                                 \
-              }                                                                                                   \
+              if ((T) < 2) wv::lds_st8(aS1 + offE, (unsigned)o);                                                  \
+              if ((T) == 1) wv::lds_st8(aS2 + offE, (unsigned)o);                                                 \
+              if ((T) != 9) wv::lds_st8(aS3 + offE, (unsigned)o);                                                 \
+              if ((T) < 2) wv::lds_st8(aS4 + offE, (unsigned)o);                                                  \
             }                                                                                                     \
           }                                                                                                       \
           en = enN;                                                                                               \
@@ -2265,6 +2245,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         I4_STEP(0) I4_STEP(1) I4_STEP(2) I4_STEP(3) I4_STEP(4) I4_STEP(5) I4_STEP(6) I4_STEP(7) I4_STEP(8) I4_STEP(9)
 #undef I4_STEP
 #undef I4_BODY
+      }
       }
 
       PH(4);  // block chain

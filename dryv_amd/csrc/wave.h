@@ -19,6 +19,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define DRYV_WAVE_IMPL
 #include <hip/hip_runtime.h>
 #define WV __device__ __forceinline__
+// a region that only the lanes with `cond` enter, around code that keeps its own per-lane predicates (so that the lane
+// emulator, whose every lane must walk through the region's wave_sync calls, can take all lanes through it)
+#define WV_LANES_IF(cond) if (cond)
 
 namespace wv {
 

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #define WV static inline
+#define WV_LANES_IF(cond) if (true)
 
 namespace wv {
 
