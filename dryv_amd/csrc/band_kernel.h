@@ -2171,30 +2171,16 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
         // for the one-block rounds; then entry and residual one round ahead
         const unsigned sq0 = wv::lds_u32(seqA), sq1 = wv::lds_u32(seqA + 4), sq2 = wv::lds_u32(seqA + 8);
         const unsigned sS0 = wv::lds_u32(seqA - 12 * ch), sS2 = wv::lds_u32(seqA - 12 * ch + 8);
-        u32x4 en = u32x4{wv::lds_u32(entB + (int)(sS0 & 0xffu)), wv::lds_u32(entS + (int)(sS0 & 0xffu)), 0u, 0u};
+        u32x3 en = u32x3{wv::lds_u32(entB + (int)(sS0 & 0xffu)), wv::lds_u32(entS + (int)(sS0 & 0xffu)), 0u};
         unsigned rr = (unsigned)wv::lds_i16(resS);
         const unsigned dcRounds = (unsigned)wv::rfl((int)wv::lds_u32(ts + S_INFO + 32 * buf + 28));
         constexpr unsigned SEL_DC = 0x0d0d0d0du;   // the selector of the row whose value is the block's DC
 #define I4_BODY(T, DC)                                                                                           \
         {                                                                                                         \
-          const unsigned lo = wv::lds_u32(q + offE), hi = wv::lds_u32(q + offE + 4);                              \
-          u32x4 ee = u32x4{0u, 0u, 0u, 0u};                                                                       \
-          if (DC) ee = wv::lds_u128((two ? eB : eG) + offE);                                                      \
-          u32x4 enN = en;                                                                                         \
-          unsigned rrN;                                                                                           \
-          if (twoN) {                                                                                             \
-            const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                  \
-            enN = wv::lds_u128(entB + (int)mN);                                                                   \
-            rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                                       \
-          } else {                                                                                                \
-            const unsigned mN = ((TN < 4 ? sS0 : sS2) >> (8 * (TN & 3))) & 0xffu;                                 \
-            enN.x = wv::lds_u32(entB + (int)mN);                                                                  \
-            enN.y = wv::lds_u32(entS + (int)mN);                                                                  \
-            rrN = (unsigned)wv::lds_i16(resS + 32 * (4 * byN + bxN));                                             \
-          }                                                                                                       \
           unsigned dcv = 0;                                                                                       \
           if (DC) {                                                                                               \
             /* DC (pred4x4.rs:116-167) with both neighbours: (L0 + .. + L3 + T0 + .. + T3 + 4) >> 3 of the block's own array */ \
+            const u32x4 ee = wv::lds_u128((two ? eB : eG) + offE);                                                \
             dcv = wv::dot4(ee.x, 0x01000000u, wv::dot4(ee.y, 0x00010101u, wv::dot4(ee.z, 0x01010101u, 4u))) >> 3; \
           }                                                                                                       \
           if (two) {                                                                                              \
@@ -2223,8 +2209,6 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
               if ((T) < 2) wv::lds_st8(aS4 + offE, (unsigned)o);                                                  \
             }                                                                                                     \
           }                                                                                                       \
-          en = enN;                                                                                               \
-          rr = rrN;                                                                                               \
         }
 #define I4_STEP(T)                                                                                              \
         {                                                                                                         \
@@ -2238,8 +2222,25 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           /* the window's address: base + table offset behind an optimisation barrier, so that the round's constant */ \
           /* rides in the loads' immediate offset instead of being added to the base once per round */            \
           const int q = wv::opaque((two ? eB : eG) + (int)en.x);                                                  \
+          const unsigned lo = wv::lds_u32(q + offE), hi = wv::lds_u32(q + offE + 4);                              \
+          /* the next round's entry and residual: requested here, in front of the branch, so that they travel while this */ \
+          /* round computes (behind the branch the compiler merges them into the bodies' common tail, after the arithmetic) */ \
+          u32x3 enN = en;                                                                                         \
+          unsigned rrN;                                                                                           \
+          if (twoN) {                                                                                             \
+            const unsigned mN = ((TN < 4 ? sq0 : TN < 8 ? sq1 : sq2) >> (8 * (TN & 3))) & 0xffu;                  \
+            enN = wv::lds_u96(entB + (int)mN);                                                                    \
+            rrN = wv::lds_u32(resB + 32 * (4 * byN + bxN));                                                       \
+          } else {                                                                                                \
+            const unsigned mN = ((TN < 4 ? sS0 : sS2) >> (8 * (TN & 3))) & 0xffu;                                 \
+            enN.x = wv::lds_u32(entB + (int)mN);                                                                  \
+            enN.y = wv::lds_u32(entS + (int)mN);                                                                  \
+            rrN = (unsigned)wv::lds_i16(resS + 32 * (4 * byN + bxN));                                             \
+          }                                                                                                       \
           /* (wave-uniform: the mode pre-pass marked the rounds in which some block of the step takes its own DC) */ \
           if (dcRounds & (1u << (T))) I4_BODY(T, true) else I4_BODY(T, false)                                     \
+          en = enN;                                                                                               \
+          rr = rrN;                                                                                               \
           wv::wave_sync();                                                                                        \
         }
         I4_STEP(0) I4_STEP(1) I4_STEP(2) I4_STEP(3) I4_STEP(4) I4_STEP(5) I4_STEP(6) I4_STEP(7) I4_STEP(8) I4_STEP(9)

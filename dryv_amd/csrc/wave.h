@@ -7,6 +7,7 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 
 #define DPP_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 #define DPP_ROW_SHL(n) (0x100 + (n))
@@ -59,6 +60,7 @@ WV int lds_i16(int a) { return *WV_LDS(const int16_t, a); }
 WV unsigned lds_u32(int a) { return *WV_LDS(const unsigned, a); }
 WV u32x2 lds_u64(int a) { return *WV_LDS(const u32x2, a); }
 WV u32x4 lds_u128(int a) { return *WV_LDS(const u32x4, a); }
+WV u32x3 lds_u96(int a) { return *WV_LDS(const u32x3, a); }   // 16-byte aligned (ds_read_b96)
 WV void lds_st8(int a, unsigned v) { *WV_LDS(uint8_t, a) = (uint8_t)v; }
 WV void lds_st16(int a, unsigned v) { *WV_LDS(uint16_t, a) = (uint16_t)v; }
 WV void lds_st32(int a, unsigned v) { *WV_LDS(unsigned, a) = v; }

@@ -106,6 +106,7 @@ WV int lds_i16(int a) { return EMU_LD(int16_t, a); }
 WV unsigned lds_u32(int a) { return EMU_LD(unsigned, a); }
 WV u32x2 lds_u64(int a) { emu_lds_check(a, 8); u32x2 v; memcpy(&v, g_emu.lds + a, 8); return v; }
 WV u32x4 lds_u128(int a) { emu_lds_check(a, 16); if (a & 15) { fprintf(stderr, "emu: unaligned b128 %d\n", a); abort(); } u32x4 v; memcpy(&v, g_emu.lds + a, 16); return v; }
+WV u32x3 lds_u96(int a) { emu_lds_check(a, 12); if (a & 15) { fprintf(stderr, "emu: unaligned b96 %d\n", a); abort(); } u32x3 v; memcpy(&v, g_emu.lds + a, 12); return v; }
 WV void lds_st8(int a, unsigned v) { emu_lds_check(a, 1); g_emu.lds[a] = (uint8_t)v; }
 WV void lds_st16(int a, unsigned v) { emu_lds_check(a, 2); *(uint16_t*)(g_emu.lds + a) = (uint16_t)v; }
 WV void lds_st32(int a, unsigned v) { emu_lds_check(a, 4); *(unsigned*)(g_emu.lds + a) = v; }
