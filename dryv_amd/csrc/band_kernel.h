@@ -1528,6 +1528,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
   const int aFlush = wv::opaque(ts + S_STC + 8 * CW * fpl + CW * ffy + 16 * fseg);                      // + 16 * CW * row
   const unsigned oFlush = (unsigned)wv::opaque((int)((fpl ? offCr : offCb) + (unsigned)(ffy * pitchC + 16 * fseg)));  // + 8 * (r0 + row) * pitchC + 8 * xp
   const int fseg2 = wv::opaque(2 * fseg);   // 2 * segment
+  const unsigned selH0 = (unsigned)wv::opaque((int)(0x0c040c04u + 0x00010001u * (unsigned)(2 * (lane0 >> 5))));   // byte 2 * half of the source in both halves of a pair
   // the band above's bottom lines (lanes 0..1 of a row group Cb, 2..3 Cr): + (8 * r0 - 1) * pitchC + 8 * macroblock
 
   unsigned gstepC = 0;   // this wave's steps so far (BACK's count of them is in the team's F_FREE words)
@@ -1702,54 +1703,48 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
         const int leftC = ts + S_LEFTC + 16 * gc + 8 * cpl;
         const unsigned tw = wv::lds_u32(ringP + RINGC_ENT * (xC & 3) + 4 * ccx);
         const unsigned lw = wv::lds_u32(leftC + 4 * ccy);
-        unsigned src = lw, selA = 0x0c040c04u, selB = 0x0c040c04u, inc = 0x00010001u;
+        // horizontal: the left column (zero without neighbour A: quirk Q4); DC: below; plane: further below
+        unsigned src = (cmode == 1 && mbAC) ? lw : 0u;
         if (wv::any(cmode == 0)) {
-          const int st = (int)wv::sad4(tw), sl = (int)wv::sad4(lw);
           // trans_chroma.rs:168-286 incl. quirk Q2 (`> 0` where the spec means "available"):
           //   blocks (0,0),(4,4): both -> 8-sample mean; left only -> left; top only needs every top sample > 0
           //   block (4,0): top, else left if its 4th sample > 0;  block (0,4): left if its 4th sample > 0, else top if ...
-          const bool nz = (((tw - 0x01010101u) & ~tw) & 0x80808080u) == 0u;
-          const bool tAll = mbBC && nz, t3 = mbBC && (tw >> 24) != 0, l3 = mbAC && (lw >> 24) != 0;
-          const int vT = (st + 2) >> 2, vL = (sl + 2) >> 2, vB = (st + sl + 4) >> 3;
-          const int vDiag = (mbAC && mbBC) ? vB : mbAC ? vL : tAll ? vT : 128;
-          const int vTR = mbBC ? vT : l3 ? vL : 128;
-          const int vBL = l3 ? vL : t3 ? vT : 128;
-          const int v = ccx == ccy ? vDiag : ccx == 1 ? vTR : vBL;
+          const int st2 = (int)wv::sum4(tw, 2u), sl2 = (int)wv::sum4(lw, 2u);
+          const int vT = st2 >> 2, vL = sl2 >> 2;
+          int v;
+          if (!wv::any(validC && cmode == 0 && !(mbAC && mbBC))) {
+            // every DC macroblock of the step has both neighbours (all but the picture's first column and row)
+            const int vBL = (lw >> 24) != 0 ? vL : (tw >> 24) != 0 ? vT : 128;
+            v = ccx == ccy ? (st2 + sl2) >> 3 : ccx == 1 ? vT : vBL;
+          } else {
+            const bool nz = (((tw - 0x01010101u) & ~tw) & 0x80808080u) == 0u;
+            const bool tAll = mbBC && nz, t3 = mbBC && (tw >> 24) != 0, l3 = mbAC && (lw >> 24) != 0;
+            const int vDiag = (mbAC && mbBC) ? (st2 + sl2) >> 3 : mbAC ? vL : tAll ? vT : 128;
+            const int vTR = mbBC ? vT : l3 ? vL : 128;
+            const int vBL = l3 ? vL : t3 ? vT : 128;
+            v = ccx == ccy ? vDiag : ccx == 1 ? vTR : vBL;
+          }
           if (cmode == 0) src = (unsigned)v * 0x01010101u;
         }
-        if (cmode == 0) {
-        } else if (cmode == 1) {  // horizontal (zero without neighbour A: quirk Q4)
-          if (!mbAC) src = 0;
-        } else if (cmode == 2) {  // vertical
-          src = mbBC ? tw : 0u;
-          selA = 0x0c010c00u;
-          selB = 0x0c030c02u;
-          inc = 0;
-        } else {
-          src = 0;  // plane: below
-        }
-        selA += inc * (unsigned)(2 * half);  // this lane's rows: 2 * half, 2 * half + 1
-        selB += inc * (unsigned)(2 * half);
+        // vertical: the top line, pixel pairs (0, 1) and (2, 3) for both of this lane's rows; horizontal and DC: byte y of the
+        // source for both pairs of row y = 2 * half + k (one v_perm_b32 per pixel pair either way)
+        const bool isV = cmode == 2;
+        if (isV) src = mbBC ? tw : 0u;
         unsigned p01[2], p23[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          p01[k] = wv::perm(src, src, selA + inc * k);
-          p23[k] = wv::perm(src, src, selB + inc * k);
+          p01[k] = wv::perm(src, src, isV ? 0x0c010c00u : selH0 + 0x00010001u * k);
+          p23[k] = wv::perm(src, src, isV ? 0x0c030c02u : selH0 + 0x00010001u * k);
         }
         if (wv::any(validC && kindC != 3 && cmode == 3)) {
-          // plane (:319-363): H = sum (k+1)(T[4+k] - T[2-k]), V likewise on the left column; T[-1] = L[-1] = corner
-          const int k = cblk;
-          const int rT = ringP + RINGC_ENT * (xC & 3);
-          const int corner = (int)wv::lds_u8(ringP + RINGC_ENT * ((xC - 1) & 3) + 7);
-          const int ha = (int)wv::lds_u8(rT + 4 + k), hb = k == 3 ? corner : (int)wv::lds_u8(rT + 2 - k);
-          const int va = (int)wv::lds_u8(leftC + 4 + k), vb = k == 3 ? corner : (int)wv::lds_u8(leftC + 2 - k);
-          int hs = (k + 1) * (ha - hb), vs = (k + 1) * (va - vb);
-          hs += xor1(hs);
-          hs += xor2(hs);
-          vs += xor1(vs);
-          vs += xor2(vs);
+          // plane (:319-363): H = sum (k+1)(T[4+k] - T[2-k]), V likewise on the left column; T[-1] = L[-1] = corner: every lane
+          // forms both from the whole top line and left column of its plane, as two byte dot products each
+          const u32x2 tt = wv::lds_u64(ringP + RINGC_ENT * (xC & 3)), ll = wv::lds_u64(leftC);
+          const unsigned c4 = 4u * wv::lds_u8(ringP + RINGC_ENT * ((xC - 1) & 3) + 7);
+          const int hs = (int)wv::dot4(tt.y, 0x04030201u, 0u) - (int)wv::dot4(tt.x, 0x00010203u, c4);
+          const int vs = (int)wv::dot4(ll.y, 0x04030201u, 0u) - (int)wv::dot4(ll.x, 0x00010203u, c4);
           if (cmode == 3 && mbAC && mbBC) {
-            const int a = 16 * ((int)wv::lds_u8(leftC + 7) + (int)wv::lds_u8(rT + 7));
+            const int a = 16 * (int)((ll.y >> 24) + (tt.y >> 24));
             const int bq = (34 * hs + 32) >> 6, c = (34 * vs + 32) >> 6;
             // pixel (x, y) of the plane: clip255((a + b (x-3) + c (y-3) + 16) >> 5); all terms fit 16 bits
             const int base = a + bq * (4 * ccx - 3) + c * (4 * ccy + 2 * half - 3) + 16;
@@ -1818,7 +1813,8 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
       wv::wave_sync();
       // flush the staged rows: every NSC-th macroblock, or at the end of a row: 8 * NSC contiguous bytes per pixel row.
       EXP_REP(8)
-      if (!EXP_SKIP(8) && wv::any(valid && (slot == NSC - 1 || x == W - 1))) {
+      // (scalar pre-test: a row flushes at x = NSC - 1 mod NSC or x = W - 1, and every row's x has the parity of s)
+      if (!EXP_SKIP(8) && ((s & 1) != 0 || ((W - 1 - s) & 1) == 0)) {
         constexpr int LR = 8 * NSC;  // lanes per macroblock row: 2 planes x 8 pixel rows x NSC / 2 segments of 16 bytes
 #pragma unroll
         for (int it = 0; it < NSC / 2; it++) {
@@ -2029,6 +2025,8 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
   uint8_t* planeY = A.yuv;
   unsigned* handMy = A.handoff;   // the band's hand-off records (if it has a band below)
   int par = 0;  // task parity (row 0's luma ring)
+  // flush with 64 lanes per macroblock row (NSY = 4): lane = (pixel row, 16-byte segment)
+  const unsigned flushLane = (unsigned)wv::opaque(((lane0 / NSY) & 15) * pitchY + 16 * (lane0 % NSY));
 
   for (unsigned gstep = 0;; gstep++) {
     const int buf = (int)(gstep % (unsigned)NBUF);
@@ -2287,7 +2285,8 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       wv::wave_sync();
       // flush the staged rows: every NSY-th macroblock, or at the end of a row: 16 * NSY contiguous bytes per pixel row.
       EXP_REP(5)
-      if (!EXP_SKIP(5) && wv::any(valid && ((x & (NSY - 1)) == NSY - 1 || x == W - 1))) {
+      // (scalar pre-test: a row flushes at x = NSY - 1 mod NSY or x = W - 1, and every row's x has the parity of s)
+      if (!EXP_SKIP(5) && ((s & 1) != 0 || ((W - 1 - s) & 1) == 0)) {
         constexpr int LR = 16 * NSY;  // lanes per macroblock row: 16 pixel rows x NSY segments of 16 bytes
 #pragma unroll
         for (int it = 0; it < NSY; it++) {
@@ -2301,7 +2300,11 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
           const bool ok = rowFlush && xp + seg <= fx;
           const int src = ts + S_TILE + TILE_BYTES * (NP * fg + (seg >> 1)) + TILE_STRIDE * (fy + 1) + 8 + 16 * (seg & 1);
           const u32x2 lo = wv::lds_u64(src), hi = wv::lds_u64(src + 8);
-          if (ok) wv::st_g128(planeY + (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + seg)), u32x4{lo.x, lo.y, hi.x, hi.y});
+          // (the lane's part of the address -- its pixel row and segment -- is a constant of the kernel when a macroblock row
+          // takes the whole wave: flushLane; the row's part is wave-uniform)
+          const unsigned off = LR == 64 ? flushLane + (unsigned)(16 * (r0 + fg) * pitchY + 16 * xp)
+                                        : (unsigned)((16 * (r0 + fg) + fy) * pitchY + 16 * (xp + seg));
+          if (ok) wv::st_g128(planeY + off, u32x4{lo.x, lo.y, hi.x, hi.y});
         }
       }
       wv::wave_sync();
