@@ -362,21 +362,31 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
     wv::lds_st16(ldsBase + T_THR4 + 2 * k, P.thr4[k]);
     wv::lds_st16(ldsBase + T_THR8 + 2 * k, P.thr8[k]);
   }
+  // The packed path's row of a qp below 24, where the dequantisation shifts right ((c * LS + 2^(3 - qp/6)) >> (4 - qp/6)): when
+  // every LevelScale entry of qp % 6 is a multiple of 2^(4 - qp/6) -- the flat lists: 16 * normAdjust -- the row holds
+  // LS >> (4 - qp/6) and the pass neither rounds nor shifts: c * (LS >> s) is exactly (c * LS + 2^(s - 1)) >> s
+  auto folded_shr = [&](int qd, int qm) -> int {
+    if (qd >= 4) return 0;
+    unsigned all = 0;
+    for (int k = 0; k < 16; k++) all |= (unsigned)P.ls4z[16 * qm + k];
+    return (all & ((1u << (4 - qd)) - 1u)) == 0u ? 4 - qd : 0;
+  };
   for (int k = tid; k < 832; k += nthreads) {
     const int qp = k >> 4, qd = qp / 6, qm = qp - 6 * qd;
-    const unsigned v = (unsigned)P.ls4z[16 * qm + (k & 15)] << (qd > 4 ? qd - 4 : 0);
+    const unsigned v = ((unsigned)P.ls4z[16 * qm + (k & 15)] << (qd > 4 ? qd - 4 : 0)) >> folded_shr(qd, qm);
     wv::lds_st16(ldsBase + T_LS4Q + 2 * k, v > 0xFFFFu ? 0xFFFFu : v);
   }
   for (int qp = tid; qp < 52; qp += nthreads) {
     const int qd = qp / 6, qm = qp - 6 * qd;
+    const int fold = folded_shr(qd, qm);
     unsigned m = 0;
-    for (int k = 0; k < 16; k++) m = max(m, (unsigned)P.ls4z[16 * qm + k] << (qd > 4 ? qd - 4 : 0));
+    for (int k = 0; k < 16; k++) m = max(m, ((unsigned)P.ls4z[16 * qm + k] << (qd > 4 ? qd - 4 : 0)) >> fold);
     m = m > 0xFFFFu ? 0xFFFFu : m;
     wv::lds_st16(ldsBase + T_LSMAX + 2 * qp, m);
     // d = ((c * LS) << shl + rnd) >> shr with shl = max(qp/6 - 4, 0), shr = max(4 - qp/6, 0), rnd = 2^(3 - qp/6) below qp 24
     const unsigned shl = qd > 4 ? qd - 4 : 0, shr = qd < 4 ? 4 - qd : 0, rnd = qd < 4 ? 1u << (3 - qd) : 0u;
-    wv::lds_st32(ldsBase + T_QP + 32 * qp, rnd * 0x10001u);
-    wv::lds_st32(ldsBase + T_QP + 32 * qp + 4, shr * 0x10001u);
+    wv::lds_st32(ldsBase + T_QP + 32 * qp, fold ? 0u : rnd * 0x10001u);
+    wv::lds_st32(ldsBase + T_QP + 32 * qp + 4, fold ? 0u : shr * 0x10001u);
     wv::lds_st32(ldsBase + T_QP + 32 * qp + 8, m | ((unsigned)P.thr4[qp] << 16));
     wv::lds_st32(ldsBase + T_QP + 32 * qp + 12, shl | (rnd << 8) | (shr << 16) | ((unsigned)(32 * qm) << 24));
     // Intra16x16 DC (pred16x16.rs:465-479): qp >= 36: (f * LS) << (qp/6 - 6), else (f * LS + 2^(5 - qp/6)) >> (6 - qp/6)
