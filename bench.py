@@ -33,35 +33,55 @@ def launch_ranks(n, argv):
     """`python bench.py --gpus N` typed as is (no torch.distributed.run around it): the parent starts N fresh child processes,
     one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's JSON line and
     exits non-zero if any rank fails. It runs before this process has made any GPU call (nothing here imports torch or the
-    library), and the children are new processes, never an exec of one that has touched the GPU."""
+    library), and the children are new processes, never an exec of one that has touched the GPU. All children are polled:
+    when one of them fails, the others -- which would sit in the rendezvous or a collective until torch's timeout -- are
+    ended and the launcher returns at once."""
     import subprocess
+    import tempfile
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0]
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(rc != 0 for rc in rcs):
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        failed = False
+        while True:
+            rcs = [p.poll() for p in procs]
+            if any(rc not in (None, 0) for rc in rcs):
+                failed = True
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            time.sleep(0.05)
+        if failed:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 5.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        rcs = [p.returncode for p in procs]
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    if failed:
         sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
-        sys.stdout.write(out0)
         return 1
-    sys.stdout.write(out0)
-    sys.stdout.flush()
     return 0
 
 
 def kernel_source_sha():
-    """sha256 (16 hex digits) over the sources of the kernel the bench measures: measured HBM traffic is only quoted
-    for the build it was measured on."""
+    """sha256 (16 hex digits) over the sources of the kernel the bench measures, its tables, its launch geometry and the
+    library code that launches it: measured HBM traffic is only quoted for the build it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("band_kernel.h", "recon_band.hip", "wave.h"):
+    for f in ("band_kernel.h", "band_diag.h", "recon_band.hip", "wave.h", "kparams.h", "recon_params.h", "band_launch.h", "recon_api.hip"):
         with open(os.path.join(ROOT, "dryv_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -112,6 +132,52 @@ def cpu_baseline(fp, mbs, coeffs, n_frames, gpu_out, frame_bytes, sample_frames)
     return out
 
 
+def secondary_line(name, device, dev_index, steps, warmup, cpu_frames):
+    """BASELINE.json's other single-GPU configuration (configs[2]: 4K, 8x8 transform), measured in the same process after
+    the primary workload's timed region: kernel time from the library's HIP events, wall time per step, first and last
+    frame against the oracle, and the oracle's rate on a few frames as its CPU baseline."""
+    import oracle
+    cid, w, h, frames, t8, kw = synth.WORKLOADS[name]
+    fp = dryv_amd.make_frame_params(w, h, transform_8x8=t8)
+    per = w * h
+    mbs, coeffs = synth.generate(fp, synth.config(**kw), cid, 0, frames)
+    d_mbs = torch.from_numpy(mbs.view(np.uint8).reshape(-1)).to(device)
+    d_coeffs = torch.from_numpy(coeffs).to(device)
+    d_out = torch.zeros(frames * per * 384, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+    with dryv_amd.ReconContext(dev_index) as ctx:
+        def run(n):
+            for _ in range(n):
+                ctx.submit_device_queued(fp, frames, d_mbs.data_ptr(), d_coeffs.data_ptr(), d_out.data_ptr())
+            ctx.sync()
+            return ctx.kernel_ms_stats(n)[0]
+        run(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms = run(steps)
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3 / steps
+    verified = True
+    for fidx in sorted({0, frames - 1}):
+        st, want = oracle.reconstruct(fp, 1, mbs[fidx * per:(fidx + 1) * per], coeffs[fidx * per:(fidx + 1) * per])
+        got = d_out[fidx * per * 384:(fidx + 1) * per * 384].cpu().numpy()
+        verified = verified and st == 0 and bool(np.array_equal(got, want))
+    k = min(cpu_frames, frames)
+    t0 = time.perf_counter()
+    st, want = oracle.reconstruct(fp, k, mbs[:k * per], coeffs[:k * per])
+    dt = time.perf_counter() - t0
+    verified = verified and st == 0 and bool(np.array_equal(d_out[:k * per * 384].cpu().numpy(), want))
+    n_mbs = frames * per
+    return {"workload": "%s: %dx%d macroblocks x %d frames, resident in HBM" % (name, w, h, frames),
+            "value": n_mbs / (wall_ms * 1e-3), "unit": "macroblocks/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": wall_ms, "kernel_ms_avg": kernel_ms,
+            "frac": n_mbs * ALG_BYTES_PER_MB / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_wall": n_mbs * ALG_BYTES_PER_MB / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "verified_bit_exact": verified,
+            "cpu_baseline": {"value": k * per / dt, "unit": "macroblocks/s", "cores": 1, "kind": "port",
+                             "sample": "first %d frames (%d macroblocks), oracle/dryv_oracle.c -O2, %.1f s" % (k, k * per, dt)}}
+
+
 def dry_run(args, world, rank):
     """The launcher and the control plane without a GPU (tests/test_bench_launcher.py): every rank joins the process group
     over gloo, receives the parameter block and its shard from rank 0, generates the shard's first frame on the host and
@@ -135,7 +201,10 @@ def dry_run(args, world, rank):
                           "dry_run": True, "scaling": "weak",
                           "config": {"workload": args.workload, "frames_per_gpu": n_frames,
                                      "shards": [[int(a), int(b)] for a, b in table],
-                                     "ranks_reporting": len(reports), "macroblocks_per_step": sum(r[1] for r in reports)}}),
+                                     "backend": "gloo", "n_ranks_reporting": len(reports),
+                                     "ranks_reporting": len(reports), "kernel_ms_per_rank": {"min": None, "max": None},
+                                     "macroblocks_per_step": sum(r[1] for r in reports)},
+                          "cpu_baseline": None}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -164,6 +233,8 @@ def main():
     ap.add_argument("--preroll-ms", type=float, default=40.0, help="untimed device pre-roll before the warm-up steps")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="wait on the host after every step (round 1/2 behaviour) instead of queueing the steps on the stream")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary line (C3: 4K, 8x8 transform) that the default single-GPU C2 run also measures")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / control-plane rehearsal without a GPU: ranks over gloo, no reconstruction, value null")
     args = ap.parse_args()
@@ -174,6 +245,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world   # (under torch.distributed.run the launcher's world size wins)
+    if os.environ.get("DRYV_BENCH_FAIL_RANK") == str(rank):
+        sys.exit(3)   # (test hook, tests/test_bench_launcher.py: one rank dies before it joins the process group)
     if args.dry_run:
         return dry_run(args, world, rank)
     # One rank per GPU. (DRYV_BENCH_BACKEND=gloo is a rehearsal hook for boxes with fewer GPUs than ranks: the ranks
@@ -271,9 +344,10 @@ def main():
         vmin = vt.clone()
         dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(vt, op=dist.ReduceOp.MAX)
-        all_verified, kernel_ms_max = bool(vmin[0].item() == 1.0), float(vt[1].item())
+        all_verified, kernel_ms_max, kernel_ms_min = bool(vmin[0].item() == 1.0), float(vt[1].item()), float(vmin[1].item())
     else:
         all_verified, kernel_ms_max = verified, float(vt[1].item())
+        kernel_ms_min = kernel_ms_max
     if not all_verified:
         sys.exit("bench.py: a rank's shard differs from the oracle")
     kernel_name = "band_kernel"
@@ -312,21 +386,35 @@ def main():
                                    "frames sharded contiguously, one rank per GPU, no data-path collective"
                                    % (args.workload, w, h, n_frames),
                        "frames_per_gpu": n_frames, "macroblocks_per_step": total_mbs,
+                       "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
+                       "n_ranks_reporting": len(reports),
+                       "kernel_ms_per_rank": {"min": kernel_ms_min, "max": kernel_ms_max},
                        "steps_queued_on_stream": not args.sync_each_step,
                        "shards_verified_bit_exact": (world if not args.no_verify else 0),
                        "shard_checksums": ["%016x" % (r[2] & 0xFFFFFFFFFFFFFFFF) for r in reports]},
+            # frac: the contract's figure (algorithmic bytes of this rank's launch / the kernel's average duration by HIP events);
+            # frac_wall: the same bytes / this job's wall time per step (what `value` is made of: it also pays for the
+            # workspace reset in front of every launch and for whatever the queue leaves between launches)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "frac_wall": n_mbs * ALG_BYTES_PER_MB / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_source_sha": kernel_source_sha(),
                          "algorithmic_bytes_per_launch": n_mbs * ALG_BYTES_PER_MB, "vector_issue": valu},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        # the CPU path beside the GPU number at every N: rank 0 times the oracle over (a sample of) its own shard
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fp, mbs, coeffs, n_frames, d_out, frame_bytes,
                                                 args.cpu_sample_frames)
+        if world == 1 and args.workload.startswith("C2") and not args.no_secondary and not args.no_cpu_baseline:
+            ctx.close()
+            del d_mbs, d_coeffs, d_out
+            line["secondary"] = secondary_line("C3_4k_intra_8x8", device, dev_index, steps=10, warmup=3, cpu_frames=20)
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()   # (the other ranks wait here while rank 0 times the CPU baseline)
         dist.destroy_process_group()
 
 

@@ -44,7 +44,7 @@ def _run(cmd):
 
 def build_recon(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("recon_band.hip", "output_pack.hip", "deblock.hip", "recon_api.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("band_launch.h", "band_kernel.h", "wave.h", "output_pack.h", "deblock_kernel.h", "deblock_kernel_params.h",
+    deps = srcs + [os.path.join(CSRC, f) for f in ("band_launch.h", "band_kernel.h", "band_diag.h", "wave.h", "output_pack.h", "deblock_kernel.h", "deblock_kernel_params.h",
                                                    "deblock_params.h", "deblock_launch.h",
                                                    "kparams.h", "recon_params.h")] + [
                    os.path.join(HERE, "..", "include", "dryv_recon.h")]

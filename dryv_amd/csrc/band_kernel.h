@@ -65,6 +65,7 @@
 #include "../../include/dryv_recon.h"
 #include "kparams.h"
 #include "wave.h"
+#include "band_diag.h"
 
 namespace dryv {
 namespace band {
@@ -241,87 +242,6 @@ constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 #endif
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a hand-off record / progress word (about a second) before a band gives up
 constexpr unsigned TASK_END = 0xFFFFFFFFu;
-
-// Analysis only (tools/band_ablate.sh): -DDRYV_BAND_EXP_SKIP=<mask> drops phase k of the step (bit k) so that the difference
-// in SQ_INSTS_VALU against the full kernel is that phase's dynamic instruction count. Such a build reconstructs wrong
-// pictures; the shipped library is built with mask 0 and contains none of it.
-#ifndef DRYV_BAND_EXP_SKIP
-#define DRYV_BAND_EXP_SKIP 0
-#endif
-#define EXP_SKIP(k) ((((DRYV_BAND_EXP_SKIP) >> (k)) & 1) != 0)
-// The opposite measurement, which does not let the compiler simplify anything around the phase: -DDRYV_BAND_EXP_DUP=k runs
-// phase k of the step TWICE (the phases are idempotent), so that the difference in SQ_INSTS_VALU is its dynamic count.
-#ifndef DRYV_BAND_EXP_DUP
-#define DRYV_BAND_EXP_DUP (-1)
-#endif
-#define EXP_REP(k) for (int rep_ = 0, nrep_ = (DRYV_BAND_EXP_DUP) == (k) ? wv::opaque(2) : 1; rep_ < nrep_; rep_++)
-#define EXP_DUP_IS(k) ((DRYV_BAND_EXP_DUP) == (k))
-
-// Diagnostic builds only. -DDRYV_BAND_PROFILE (tools/band_phases.py): per-wave cycle sums per phase of the step.
-// -DDRYV_BAND_TRACE (tools/band_trace.py): breadcrumbs only. Both write to a buffer of their own; the shipped library
-// contains none of this.
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_BAND_TRACE)
-#define DRYV_BAND_TRACE
-#endif
-#define BAND_NPH 16
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-#define PH(k)                                                     \
-  do {                                                            \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                           \
-    phAcc[k] += now_ - phT;                                       \
-    phT = now_;                                                   \
-  } while (0)
-#elif defined(DRYV_BAND_MARK) && !defined(DRYV_EMU)
-// analysis only (tools/band_static.py): phase boundaries as comments in the assembly, to count instructions between them
-#define PH_STR2(x) #x
-#define PH_STR(x) PH_STR2(x)
-#define PH(k) asm volatile("; DRYV_MARK " PH_STR(__LINE__) " " #k ::: "memory")
-#else
-#define PH(k) do { } while (0)
-#endif
-// -DDRYV_BAND_TIMELINE (tools/band_timeline.py): per band task, 100 MHz timestamps of the claim (FRONT) and of BACK's
-// first and last step, behind the trace records
-// (with -DDRYV_BAND_TLMODES as well, tools/modes_timeline.py: the four stamps are the mode pre-pass's instead -- its start, the
-// end of its first wait for the band above, its end, and FRONT's arrival at the wait for it)
-#if defined(DRYV_BAND_TIMELINE) && !defined(DRYV_EMU)
-#define TLINE_(task, k, val)                                                                                  \
-  do {                                                                                                        \
-    if (wv::lane_id() == 0 && A.profile)                                                                      \
-      (A.profile + (size_t)65536 * (BAND_NPH + 4))[(size_t)(task) * 4 + (k)] = (unsigned long long)(val);   \
-  } while (0)
-#define TNOW() __builtin_amdgcn_s_memrealtime()
-#if defined(DRYV_BAND_TLENDS)   // (tools/ends_timeline.py: when FRONT, BACK and CHROMA finish a task, and when CHROMA begins it)
-#define TLINE(task, k, val) do { } while (0)
-#define TLM(task, k, val) do { } while (0)
-#define TLE(task, k, val) TLINE_(task, k, val)
-#elif defined(DRYV_BAND_TLMODES)
-#define TLINE(task, k, val) do { } while (0)
-#define TLM(task, k, val) TLINE_(task, k, val)
-#else
-#define TLINE(task, k, val) TLINE_(task, k, val)
-#define TLM(task, k, val) do { } while (0)
-#endif
-#else
-#define TLINE(task, k, val) do { } while (0)
-#define TLM(task, k, val) do { } while (0)
-#define TNOW() 0
-#endif
-#ifndef TLE
-#define TLE(task, k, val) do { } while (0)
-#endif
-// breadcrumbs: word k of this wave's 8-word trace record (behind the phase sums), written through so that a host
-// thread can read them while the kernel is still running
-#if defined(DRYV_BAND_TRACE) && !defined(DRYV_EMU)
-#define TRACE(k, val)                                                                                                 \
-  do {                                                                                                                \
-    if (lane0 == 0 && A.profile)                                                                                      \
-      wv::st_sc1((unsigned*)(A.profile + (size_t)65536 * BAND_NPH) + (size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * 8 + (k), \
-                 (unsigned)(val));                                                                                    \
-  } while (0)
-#else
-#define TRACE(k, val) do { } while (0)
-#endif
 
 struct Args {
   const dryv_mb_desc* mbs;
@@ -1211,12 +1131,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
 template <bool HAS_I8, bool WIDE>
 WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  unsigned long long phAcc[BAND_NPH];
-  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
-  unsigned long long phT = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
+  BAND_DIAG_BEGIN();
   const int W = P.W, H = P.H, nF = P.n_frames;
   const int nBands = (H + 3) >> 2;
   const unsigned totalTasks = (unsigned)nF * (unsigned)nBands;
@@ -1498,13 +1413,8 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
     TLE(task, 0, TNOW());
     TRACE(6, task + 1u);
   }
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
   TRACE(7, 0xD0E);
-#endif
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  if (lane0 == 0 && A.profile)
-    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
-#endif
+  BAND_DIAG_END();
 }
 
 // ==================================================================================================================
@@ -1513,12 +1423,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
 template <bool HAS_I8, bool WIDE>
 WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  unsigned long long phAcc[BAND_NPH];
-  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
-  unsigned long long phT = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
+  BAND_DIAG_BEGIN();
   const int W = P.W, H = P.H, nF = P.n_frames;
   const int nBands = (H + 3) >> 2;
   const int pitchC = W * 8;
@@ -1862,10 +1767,7 @@ WV void band_chroma(const KParams& P, const Args& A, const int ldsBase, const in
     }
     TLE(task, 2, TNOW());
   }
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  if (lane0 == 0 && A.profile)
-    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
-#endif
+  BAND_DIAG_END();
 }
 
 // ==================================================================================================================
@@ -1886,12 +1788,7 @@ WV void top_border(int ts, int g, int x, int par, int i) {
 // other), and says so; BACK waits for that before it frees the record and writes the step out.
 WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  unsigned long long phAcc[BAND_NPH];
-  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
-  unsigned long long phT = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
+  BAND_DIAG_BEGIN();
   const int W = P.W, H = P.H, nF = P.n_frames;
   BandGeo G = band_geo(0u, nF, W, H);
   int par = 0;
@@ -2011,21 +1908,13 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
     wv::wave_sync();
     if (lane == 0) wv::lds_st32(ts + S_F8 + F8_DONE, gstep + 1);
   }
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  if (lane0 == 0 && A.profile)
-    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
-#endif
+  BAND_DIAG_END();
 }
 
 template <bool HAS_I8>
 WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  unsigned long long phAcc[BAND_NPH];
-  for (int k = 0; k < BAND_NPH; k++) phAcc[k] = 0;
-  unsigned long long phT = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
+  BAND_DIAG_BEGIN();
   const int W = P.W, H = P.H, nF = P.n_frames;
   const int nBands = (H + 3) >> 2;
   const int pitchY = W * 16;
@@ -2323,10 +2212,7 @@ WV void band_back(const KParams& P, const Args& A, const int ldsBase, const int 
       if (s == G.nSteps - 1) TLINE(task, 2, TNOW());
       if (s == G.nSteps - 1) TLE(task, 1, TNOW());
   }
-#if defined(DRYV_BAND_PROFILE) && !defined(DRYV_EMU)
-  if (lane0 == 0 && A.profile)
-    for (int k = 0; k < BAND_NPH; k++) A.profile[(size_t)(A.waveBase + (int)(threadIdx.x >> 6)) * BAND_NPH + k] = phAcc[k];
-#endif
+  BAND_DIAG_END();
 }
 
 }  // namespace band

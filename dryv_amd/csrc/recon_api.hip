@@ -209,6 +209,10 @@ int finish(dryv_recon_ctx* ctx) {
   if (*ctx->h_status & 2u) {
     ctx->wide_reruns++;
     ctx->last_band = true;
+    // What the batches that are NOT run again have reported stays reported: an unsupported record (bit 0) or a band that
+    // gave up waiting (bit 2, with where) in front of the first flagged batch of a queue would otherwise vanish with the
+    // status words that the re-run starts from
+    const unsigned keep = ctx->h_status[0] & 5u, keep1 = ctx->h_status[1], keep2 = ctx->h_status[2], keep3 = ctx->h_status[3];
     e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream);
     if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(status)");
     int st = DRYV_OK;
@@ -228,6 +232,12 @@ int finish(dryv_recon_ctx* ctx) {
     if (st != DRYV_OK) return st;
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
+    if ((keep & 4u) && !(ctx->h_status[0] & 4u)) {
+      ctx->h_status[1] = keep1;
+      ctx->h_status[2] = keep2;
+      ctx->h_status[3] = keep3;
+    }
+    ctx->h_status[0] |= keep;
   }
   if (ctx->last_band && (*ctx->h_status & 4u)) {
     char msg[160];

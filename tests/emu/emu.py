@@ -16,7 +16,7 @@ def build(force=False, defs=()):
     SO = os.path.join(HERE, "libdryv_emu%s.so" % "".join("_" + d.replace("-D", "").replace("=", "") for d in defs))
     csrc = os.path.join(HERE, "..", "..", "dryv_amd", "csrc")
     deps = [os.path.join(HERE, "band_emu.cpp"), os.path.join(HERE, "wave_emu.h")] + [os.path.join(csrc, f) for f in
-                                                    ("band_kernel.h", "wave.h", "kparams.h", "recon_params.h", "deblock_kernel.h",
+                                                    ("band_kernel.h", "band_diag.h", "wave.h", "kparams.h", "recon_params.h", "deblock_kernel.h",
                                                      "deblock_kernel_params.h", "deblock_params.h")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         r = subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DDRYV_EMU", "-Wall",

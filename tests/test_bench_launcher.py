@@ -27,7 +27,10 @@ def test_bench_starts_its_own_ranks(n):
     assert len(lines) == 1, r.stdout          # exactly one JSON line, rank 0's
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["dry_run"] is True and d["value"] is None
-    assert d["config"]["ranks_reporting"] == n
+    assert d["config"]["ranks_reporting"] == n and d["config"]["n_ranks_reporting"] == n
+    # the keys an N > 1 line carries so that a scaling record shows who took part (values are null without a GPU)
+    assert d["config"]["backend"] == "gloo" and set(d["config"]["kernel_ms_per_rank"]) == {"min", "max"}
+    assert "cpu_baseline" in d
     assert d["config"]["shards"] == [[3 * k, 3] for k in range(n)]
     assert d["config"]["macroblocks_per_step"] == n * 3 * 120 * 68
 
@@ -37,6 +40,18 @@ def test_launcher_fails_when_a_rank_fails():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--workload", "no_such_workload"], env=_env(),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_launcher_ends_the_other_ranks_when_one_fails():
+    # only rank 1 dies (before the rendezvous): rank 0 would wait in init_process_group for torch's timeout; the launcher
+    # polls all children, ends the survivors and returns at once
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--frames-per-gpu", "2"],
+                       env=dict(_env(), DRYV_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 60
+    assert "rank exit codes" in r.stderr
 
 
 def test_single_process_under_an_external_launcher_is_not_relaunched():

@@ -277,6 +277,40 @@ def test_queued_device_submits(recon_ctx):
             assert st == 0 and np.array_equal(d_o.cpu().numpy(), want), "queued batch %d" % k
 
 
+def test_queue_keeps_status_of_batches_not_rerun(recon_ctx):
+    """A queue [batch with an unsupported record, ordinary batch, batch beyond the 32-bit path]: the wide re-run at sync
+    starts at the third batch and clears the device's status words first -- what the first batch reported must survive
+    it (DRYV_E_UNSUPPORTED, the record reconstructed as zero), and only one batch is run again."""
+    import torch
+    fp = abi.make_frame_params(11, 9)
+    cases = []
+    for k, kind in enumerate(["bad", "plain", "big"]):
+        cfg = synth.config(i4x4=0.6, qp=(51, 51), coded=1.0) if kind == "big" else synth.config(i4x4=0.6)
+        mbs, co = synth.generate(fp, cfg, 400 + k, 0, 3)
+        if kind == "big":
+            co = np.where(np.arange(co.size).reshape(co.shape) % 2 == 0, 32767, -32768).astype(np.int16)
+        if kind == "bad":
+            mbs = mbs.copy()
+            mbs.view(np.uint8).reshape(-1, 16)[40, 0] = 7   # mb_kind 7: not a macroblock kind of this path
+        cases.append((mbs, co))
+    ev0, nb0 = recon_ctx.wide_rerun_stats()
+    bufs = []
+    for mbs, co in cases:
+        bufs.append((torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda(), torch.from_numpy(co).cuda(),
+                     torch.zeros(3 * 99 * 384, dtype=torch.uint8, device="cuda")))
+    torch.cuda.synchronize()
+    for d_m, d_c, d_o in bufs:
+        recon_ctx.submit_device_queued(fp, 3, d_m.data_ptr(), d_c.data_ptr(), d_o.data_ptr())
+    with pytest.raises(ReconError) as e:
+        recon_ctx.sync()
+    assert e.value.status == abi.DRYV_E_UNSUPPORTED
+    ev1, nb1 = recon_ctx.wide_rerun_stats()
+    assert (ev1 - ev0, nb1 - nb0) == (1, 1)
+    for (mbs, co), (d_m, d_c, d_o) in zip(cases[1:], bufs[1:]):   # the batches behind it are whole
+        st, want = oracle.reconstruct(fp, 3, mbs, co)
+        assert st == 0 and np.array_equal(d_o.cpu().numpy(), want)
+
+
 def test_queue_cannot_outgrow_its_workspace():
     """A queued batch that needs a larger workspace than the queue is running on is refused (DRYV_E_STATE: sync first), not
     launched: a context of its own, so that the workspace is known to be the first batch's; every buffer is full size."""
