@@ -165,23 +165,27 @@ constexpr int S_CARRYM = S_LEFTC + 64;            // u32 [4]     mode pre-pass: 
 constexpr int S_EDGE = S_CARRYM + 64;             // u8 [4][20][16]  the edge arrays (E_*) of the step's macroblocks, a row group every E_ROW
 constexpr int S_BYTES = (S_EDGE + 4 * E_ROW + 4 * E_SLOT + 63) & ~63;   // (+ 4 slots: the dump bytes reach that far beyond the last row group's)
 // builds that serve the 8x8 transform (HAS_I8) append, per team:
-constexpr int S_C8 = S_BYTES;          // i16 [4][4 blk8][8][8]  FRONT: an Intra8x8 macroblock's coefficients in raster order (the packed form:
-                                       //           pair-interleaved, T_ZZ8P); a block every C8_BLK bytes, a macroblock every C8_MB: the
-                                       //           lanes that address their blocks alike land 4 banks apart (a 128-byte stride put the
-                                       //           eight of a 32-lane group on ONE bank)
-constexpr int C8_BLK = 144, C8_MB = 4 * C8_BLK;
-constexpr int S_E8 = S_C8 + 4 * C8_MB;  // [4][128]  BACK8: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16 (L7..L0, TL,
+// (FRONT -> BACK8: an Intra8x8 macroblock's coefficients travel in the record itself, in its row group's part of S_RES, where
+// BACK8 later puts the residuals: in raster order (the packed form: pair-interleaved, T_ZZ8P); a block every C8_BLK bytes, a
+// macroblock every C8_MB = RES_ROW: the lanes that address their blocks alike land 2 banks apart (a 128-byte stride put the
+// eight of a 32-lane group on ONE bank); 8-byte aligned: the passes read it with ds_read_b64)
+constexpr int C8_BLK = 136, C8_MB = 4 * C8_BLK;
+static_assert(C8_MB == RES_ROW, "an Intra8x8 macroblock's coefficients take its residuals' place in the record");
+constexpr int S_E8 = S_BYTES;           // [4][128]  BACK8: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16 (L7..L0, TL,
                                        //           T0..T15), then E1 once more as bytes for the DC sums (L7..L0 at 112, T0..T7 at 120)
 constexpr int S_F8 = S_E8 + 512;       // u32 [16]  flags between BACK and BACK8: b8Done (BACK8 -> BACK: Intra8x8 macroblocks of step n - 1 are in
                                        //           the tiles), woDone (BACK -> BACK8: the write-out of step n - 1 is through)
 constexpr int F8_DONE = 0, F8_WO = 4;
-constexpr int S_G8 = S_F8 + 64;        // FRONT: row-pass output. 32-bit passes: T [4][2 blk8][8][8] (T: 4 bytes; 8 in the WIDE build, whose teams
-                                       //           are that much larger); packed form: i16 [4][4 blk8][8][8] with S_C8's strides, the four
+constexpr int G8_BLK = 144, G8_MB = 4 * G8_BLK;
+constexpr int S_MREC_I8 = S_F8 + 64;   // [64][32]  (the mode pre-pass's staging area, as S_MREC below, in the builds with the 8x8 transform)
+constexpr int S_G8 = S_MREC_I8 + 2048; // BACK8: row-pass output. 32-bit passes: T [4][2 blk8][8][8] (T: 4 bytes; 8 in the WIDE build, whose teams
+                                       //           are that much larger); packed form: i16 [4][4 blk8][8][8] with G8_BLK / G8_MB strides, the four
                                        //           column pairs of row r rotated by r >> 1 (rows written and columns read without conflicts)
 // builds without it append instead:
-constexpr int S_MREC = S_BYTES;        // [64][32]  FRONT: the mode records of a pre-pass iteration, on their way to memory as whole lines (the 8x8
-                                       //           builds have no room for it: 5 x 31.4 KB per CU; theirs leave lane by lane)
-constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * C8_MB) : S_BYTES + 2048; }
+constexpr int S_MREC = S_BYTES;        // [64][32]  the wave that derives the modes: the mode records of a pre-pass iteration, on their way to memory
+                                       //           as whole lines
+constexpr int mrec_off(bool hasI8) { return hasI8 ? S_MREC_I8 : S_MREC; }
+constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * G8_MB) : S_BYTES + 2048; }
 static_assert(S_EDGE % 16 == 0 && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
 // two steps ahead of BACK -- also across a task boundary, hence one ring per task parity.
@@ -642,9 +646,9 @@ WV void idct8(const T d[8], T o[8]) {
 
 // Two passes over the macroblock's four 8x8 blocks, two blocks per pass; the 16 lanes of a macroblock are (block, row),
 // then (block, column), with the row-pass output transposed through LDS. In: the coefficients already in raster order
-// in S_C8. Out: out[4 * pass + m] = rows 2m, 2m+1 of this lane's column as a saturated int16 pair.
+// at c8 (the record's coefficient area). Out: out[4 * pass + m] = rows 2m, 2m+1 of this lane's column as a saturated int16 pair.
 template <typename T>
-WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts, unsigned out[8]) {
+WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts, int c8, unsigned out[8]) {
   const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
   // qp >= 36: (c * LS) << (qp/6 - 6), else (c * LS + 2^(5 - qp/6)) >> (6 - qp/6)   (pred8x8.rs:73-78)
   const int shl = max(qd - 6, 0), shr = max(6 - qd, 0), rnd = qd < 6 ? (1 << (5 - qd)) : 0;
@@ -654,9 +658,9 @@ WV void residual8x8_passes(bool mine, int g, int i, int qp, int ldsBase, int ts,
     const int b8 = 2 * p + (i >> 3), r = i & 7;
     T dd[8], oo[8];
     if (mine) {
-      const u32x4 cr = wv::lds_u128(ts + S_C8 + C8_MB * g + C8_BLK * b8 + 16 * r);
+      const u32x2 ca = wv::lds_u64(c8 + C8_MB * g + C8_BLK * b8 + 16 * r), cb = wv::lds_u64(c8 + C8_MB * g + C8_BLK * b8 + 16 * r + 8);
       const u32x4 lr = wv::lds_u128(ldsBase + T_LS8 + 128 * qm + 16 * r);
-      const unsigned cw[4] = {cr.x, cr.y, cr.z, cr.w}, lw[4] = {lr.x, lr.y, lr.z, lr.w};
+      const unsigned cw[4] = {ca.x, ca.y, cb.x, cb.y}, lw[4] = {lr.x, lr.y, lr.z, lr.w};
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int c = (j & 1) ? ((int)cw[j >> 1] >> 16) : (int)(int16_t)cw[j >> 1];
@@ -723,24 +727,30 @@ WV void idct8_pk(const unsigned d[8], unsigned o[8]) {
 
 // The packed 16-bit form (exact under T_THR8P's bound, which the caller has checked for every Intra8x8 block of the step):
 // ONE pass over the macroblock's four blocks. Lane i of the macroblock: block i >> 2, rows 2p and 2p + 1 (p = i & 3) in
-// the halves of a register, then columns 2p and 2p + 1. In: the coefficients in S_C8, pair-interleaved (T_ZZ8P). Out: out[k] =
+// the halves of a register, then columns 2p and 2p + 1. In: the coefficients at c8, pair-interleaved (T_ZZ8P). Out: out[k] =
 // row k, columns 2p | 2p + 1 << 16 of block i >> 2.
-WV void residual8x8_pk16(bool mine, int lane, int qp, int ldsBase, int ts, unsigned out[8]) {
+WV void residual8x8_pk16(bool mine, int lane, int qp, int ldsBase, int ts, int c8, unsigned out[8]) {
   const int g = lane >> 4, i = lane & 15, p = i & 3;
-  const int blk = ts + S_C8 + C8_MB * g + C8_BLK * (i >> 2), g8 = ts + S_G8 + C8_MB * g + C8_BLK * (i >> 2);
+  const int blk = c8 + C8_MB * g + C8_BLK * (i >> 2), g8 = ts + S_G8 + G8_MB * g + G8_BLK * (i >> 2);
   // S_G8: (row r, column pair q) of the block at dword 4 r + ((q + (r >> 1)) & 3)
   const int sw[4] = {4 * (p & 3), 4 * ((p + 1) & 3), 4 * ((p + 2) & 3), 4 * ((p + 3) & 3)};
+  const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
+  const unsigned shl2 = (unsigned)max(qd - 6, 0) * 0x10001u, shr2 = (unsigned)max(6 - qd, 0) * 0x10001u;
+  const unsigned rnd2 = qd < 6 ? (0x10001u << (5 - qd)) : 0u;
+  const bool anyShl = wv::any(mine && shl2 != 0u);   // (qp >= 42 only: shl or shr is 0)
   if (mine) {
-    const int qd = (qp * 43) >> 8, qm = qp - 6 * qd;
-    const unsigned shl2 = (unsigned)max(qd - 6, 0) * 0x10001u, shr2 = (unsigned)max(6 - qd, 0) * 0x10001u;
-    const unsigned rnd2 = qd < 6 ? (0x10001u << (5 - qd)) : 0u;
     unsigned dd[8], oo[8];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const u32x4 r = wv::lds_u128(blk + 32 * p + 16 * h), l = wv::lds_u128(ldsBase + T_LS8P + 128 * qm + 32 * p + 16 * h);
-      const unsigned rw[4] = {r.x, r.y, r.z, r.w}, lw[4] = {l.x, l.y, l.z, l.w};
+      const u32x2 ra = wv::lds_u64(blk + 32 * p + 16 * h), rb = wv::lds_u64(blk + 32 * p + 16 * h + 8);
+      const u32x4 l = wv::lds_u128(ldsBase + T_LS8P + 128 * qm + 32 * p + 16 * h);
+      const unsigned rw[4] = {ra.x, ra.y, rb.x, rb.y}, lw[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
-      for (int j = 0; j < 4; j++) dd[4 * h + j] = wv::pk_ashr(wv::pk_shl(wv::pk_mad(rw[j], lw[j], rnd2), shl2), shr2);   // (shl or shr is 0)
+      for (int j = 0; j < 4; j++) dd[4 * h + j] = wv::pk_ashr(wv::pk_mad(rw[j], lw[j], rnd2), shr2);
+    }
+    if (anyShl) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) dd[j] = wv::pk_shl(dd[j], shl2);
     }
     idct8_pk(dd, oo);
 #pragma unroll
@@ -759,15 +769,19 @@ WV void residual8x8_pk16(bool mine, int lane, int qp, int ldsBase, int ts, unsig
 #pragma unroll
     for (int k = 0; k < 8; k++) out[k] = wv::pk_ashr6(oo[k]);
   }
-  wv::wave_sync();  // (S_C8 / S_G8 are reused by the next step)
+  wv::wave_sync();  // (the coefficient area becomes the residuals'; S_G8 is reused by the next step)
 }
 
+// The 8x8 residuals are FRONT's and BACK8's: FRONT, which holds the coefficients, checks them and scatters them into the
+// record (its row group's part of S_RES) in the order the passes read; BACK8 runs the passes when it takes the record (it used to idle half of
+// every step while FRONT, the wave every other one of the team waits for, carried them).
+constexpr unsigned I8F_PK = 1u, I8F_WIDE = 2u;   // the step's Intra8x8 residuals: in the packed 16-bit form / in 64-bit arithmetic
 // c0/c1: the 16 list entries this lane loaded: entries 16 * (i & 3) .. +15 of 8x8 block i >> 2. mine: this lane's macroblock
 // is a valid Intra8x8 one. Overflow handling as in residual_pass (thr8: |d| <= 2^23 keeps both 8-point passes in int32).
-// Returns whether the step took the packed form (wave-uniform): `out` is then in residual8x8_pk16's layout.
+// Returns the form the passes take (wave-uniform: I8F_*).
 template <bool WIDE>
-WV bool residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp, int ldsBase, int ts, unsigned* status,
-                    unsigned batchSeq, unsigned out[8]) {
+WV unsigned residual8x8_scatter(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp, int ldsBase, int c8, unsigned* status,
+                                unsigned batchSeq) {
   const int g = lane >> 4, i = lane & 15;
   // the block's sum of |c| (four lanes hold a block's 64 entries) against the qp's bound of the packed form
   bool pk = false;
@@ -782,29 +796,53 @@ WV bool residual8x8(const u32x4 c0, const u32x4 c1, bool mine, int lane, int qp,
   if (!pk && wv::any(mine && thr != 0xFFFF)) big = mine && thr != 0xFFFF && max_abs16(c0, c1, false) > thr;
   // list order -> raster (frame/mod.rs:212-284) resp. the packed form's pair-interleaved block: one 16-bit store per entry
   if (mine) {
-    const int dst = ts + S_C8 + C8_MB * g + C8_BLK * (i >> 2);
+    const int dst = c8 + C8_MB * g + C8_BLK * (i >> 2);
     const u32x4 zp = wv::lds_u128(ldsBase + (pk ? T_ZZ8P : T_ZZ8) + 16 * (i & 3));
     const unsigned zw[4] = {zp.x, zp.y, zp.z, zp.w}, cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
     for (int k = 0; k < 16; k++)
       wv::lds_st16(dst + (int)((zw[k >> 2] >> (8 * (k & 3))) & 0xffu), (k & 1) ? cw[k >> 1] >> 16 : cw[k >> 1]);
   }
-  wv::wave_sync();
-  if (pk) {
-    residual8x8_pk16(mine, lane, qp, ldsBase, ts, out);
-    return true;
-  }
+  if (pk) return I8F_PK;
   if (WIDE) {
-    if (wv::any(big)) {
-      residual8x8_passes<long long>(mine, g, i, qp, ldsBase, ts, out);
-      return false;
-    }
+    if (wv::any(big)) return I8F_WIDE;
   } else if (big) {
     wv::atomic_or(status, 2u);
     wv::atomic_max(status + 4, ~batchSeq);
   }
-  residual8x8_passes<int>(mine, g, i, qp, ldsBase, ts, out);
-  return false;
+  return 0u;
+}
+// BACK8's half: the passes over what FRONT left in the record. `out`: in residual8x8_pk16's layout for I8F_PK,
+// else in residual8x8_passes'.
+template <bool WIDE>
+WV void residual8x8_run(unsigned form, bool mine, int lane, int qp, int ldsBase, int ts, int c8, unsigned out[8]) {
+  if (form & I8F_PK) residual8x8_pk16(mine, lane, qp, ldsBase, ts, c8, out);
+  else if (WIDE && (form & I8F_WIDE)) residual8x8_passes<long long>(mine, lane >> 4, lane & 15, qp, ldsBase, ts, c8, out);
+  else residual8x8_passes<int>(mine, lane >> 4, lane & 15, qp, ldsBase, ts, c8, out);
+}
+// ... and the step's Intra8x8 residuals from the passes' registers into the record, [blkIdx][y][x] like FRONT's 4x4 ones.
+// Element (row k, column j) of 8x8 block b8 goes to 4x4 block (bx, by) = (2 * (b8 & 1) + (j >> 2), 2 * (b8 >> 1) + (k >> 2)),
+// position (k & 3, j & 3).
+WV void residual8x8_store(unsigned form, int lane, int resBuf, const unsigned r[8]) {
+  const int g = lane >> 4, i = lane & 15;
+  if (form & I8F_PK) {
+    // the packed form: r[k] = row k, columns 2q | 2q + 1 of 8x8 block b8 = i >> 2 (q = i & 3): one dword of 4x4 block
+    // (2 * (b8 & 1) + (q >> 1), 2 * (b8 >> 1) + (k >> 2))
+    const int b8 = i >> 2, q = i & 3;
+    const int dst = resBuf + RES_ROW * g + 32 * (8 * (b8 >> 1) + 2 * (b8 & 1) + (q >> 1)) + 4 * (q & 1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) wv::lds_st32(dst + 128 * (k >> 2) + 8 * (k & 3), r[k]);
+  } else {
+    // this lane holds column j = i & 7 of 8x8 blocks i >> 3 (r[0..3]) and 2 + (i >> 3) (r[4..7]), rows 2m, 2m + 1 per word
+    const int j = i & 7;
+    const int dst = resBuf + RES_ROW * g + 64 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
+#pragma unroll
+    for (int pk = 0; pk < 16; pk++) {
+      const int p = pk >> 3, k = pk & 7;
+      const unsigned w = r[4 * p + (k >> 1)];
+      wv::lds_st16(dst + 256 * p + 128 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
+    }
+  }
 }
 
 
@@ -1091,17 +1129,11 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
         dcMask = 0u;
       }
       if (HAS_I8 && is8) w0 = ((unsigned)M[0] << 4) | ((unsigned)M[2] << 12) | ((unsigned)M[8] << 20) | ((unsigned)M[10] << 28);
-      if (HAS_I8) {
-        if (valid) {
-          unsigned* rec = recF + (size_t)MREC_WORDS * mb;
-          wv::st_g128_sc1(rec, u32x4{w0, w1, w2, w3});
-          wv::st_g128_sc1(rec + 4, u32x4{w4, word0, dcMask, bottom});
-        }
-      } else {
+      {
         // The 64 records of the iteration are 2 KB of contiguous memory: through LDS, so that each of the two store
         // instructions writes whole lines -- lane by lane (16 of every 32 bytes per instruction) every write-through store
         // reaches memory as a partial line of its own: 1.4 M write requests more per 300 pictures, and 3 % of the launch
-        const int stg = ts + S_MREC;
+        const int stg = ts + mrec_off(HAS_I8);
         unsigned* rec0 = recF + (size_t)MREC_WORDS * (unsigned)((G.r0 + g) * W + x0);   // the batch's first record
         wv::lds_st128(stg + 32 * lane, u32x4{w0, w1, w2, w3});
         wv::lds_st128(stg + 32 * lane + 16, u32x4{w4, word0, dcMask, bottom});
@@ -1285,7 +1317,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       PH(1);  // record decode
       // ================= residuals ================================================================================
       unsigned rA[8];
-      bool pk8 = false;   // (wave-uniform) the step's Intra8x8 residuals come in the packed form's layout
+      unsigned form8 = 0;   // (wave-uniform) the form BACK8's passes over the step's Intra8x8 coefficients take (I8F_*)
       EXP_REP(0)
       if (EXP_SKIP(0)) {
 #pragma unroll
@@ -1328,12 +1360,11 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
         const u32x4 cC0 = cA0, cC1 = cA1;
         residual_pass<WIDE>(cC0, cC1, ldsBase, qp, kind == 2, dcY, kind == 2 && dcHuge, dcWide, HAS_I8 && kind == 1, A.status, A.batchSeq, rA,
                             [&]() { if (!HAS_I8 && !EXP_DUP_IS(0)) load_coefs_luma(s + 1, kN1); });
-        // Intra8x8 macroblocks: their lanes' rA becomes 16 residuals of one column per 8x8 block pass (residual8x8)
+        // Intra8x8 macroblocks: checked here, where the coefficients are, and scattered into the record (the macroblock's part of S_RES) for BACK8,
+        // which runs the 8x8 passes (the buffer goes with the record: it is free once BACK has freed the record two back)
         if (HAS_I8 && wv::any(valid && kind == 1)) {
-          unsigned r8[8];
-          pk8 = residual8x8<WIDE>(cC0, cC1, valid && kind == 1, lane, qp, ldsBase, ts, A.status, A.batchSeq, r8);
-#pragma unroll
-          for (int k = 0; k < 8; k++) rA[k] = kind == 1 ? r8[k] : rA[k];
+          if (gstep >= (unsigned)NBUF) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - NBUF + 1);
+          form8 = residual8x8_scatter<WIDE>(cC0, cC1, valid && kind == 1, lane, qp, ldsBase, ts + S_RES + RES_BUF * buf, A.status, A.batchSeq);
         }
         if (wv::any(kind == 3)) {  // (an unsupported record: reconstructs as zero)
 #pragma unroll
@@ -1362,33 +1393,13 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
       // ---- the step's record for BACK: residuals [blkIdx][y][x], table rows, kinds. The buffer is free once BACK has
       // finished the step two back.
       if (gstep >= (unsigned)NBUF) team_wait(ts + S_FLAGS + F_FREE + 4 * buf, gstep - NBUF + 1);
-      if (HAS_I8 && kind == 1) {
-        // this lane holds column j = i & 7 of 8x8 blocks i >> 3 (rA[0..3]) and 2 + (i >> 3) (rA[4..7]), rows 2m, 2m+1 per
-        // word: element (row k, column j) goes to 4x4 block (bx, by) = (2 * (b8 & 1) + (j >> 2), 2 * (b8 >> 1) + (k >> 2)),
-        // position (k & 3, j & 3)
-        if (pk8) {
-          // the packed form: rA[k] = row k, columns 2q | 2q + 1 of 8x8 block b8 = i >> 2 (q = i & 3): one dword of 4x4 block
-          // (2 * (b8 & 1) + (q >> 1), 2 * (b8 >> 1) + (k >> 2))
-          const int b8 = i >> 2, q = i & 3;
-          const int dst = ts + S_RES + RES_BUF * buf + RES_ROW * g + 32 * (8 * (b8 >> 1) + 2 * (b8 & 1) + (q >> 1)) + 4 * (q & 1);
-#pragma unroll
-          for (int k = 0; k < 8; k++) wv::lds_st32(dst + 128 * (k >> 2) + 8 * (k & 3), rA[k]);
-        } else {
-          const int j = i & 7;
-          const int dst = ts + S_RES + RES_BUF * buf + RES_ROW * g + 64 * (i >> 3) + 32 * (j >> 2) + 2 * (j & 3);
-#pragma unroll
-          for (int pk = 0; pk < 16; pk++) {
-            const int p = pk >> 3, k = pk & 7;
-            const unsigned w = rA[4 * p + (k >> 1)];
-            wv::lds_st16(dst + 256 * p + 128 * (k >> 2) + 8 * (k & 3), (k & 1) ? w >> 16 : w);
-          }
-        }
-      } else {
+      if (!(HAS_I8 && kind == 1)) {   // (an Intra8x8 macroblock's residuals: BACK8's)
         const int dst = ts + S_RES + RES_BUF * buf + hResOff;
         wv::lds_st128(dst, u32x4{rA[0], rA[1], rA[2], rA[3]});
         wv::lds_st128(dst + 16, u32x4{rA[4], rA[5], rA[6], rA[7]});
       }
-      if (i == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 4 * g, (unsigned)kind | ((unsigned)i16mode << 8));
+      // kind | Intra16x16 mode << 8 | qp << 16 | form of the step's 8x8 passes << 24
+      if (i == 0) wv::lds_st32(ts + S_INFO + 32 * buf + 4 * g, (unsigned)kind | ((unsigned)i16mode << 8) | ((unsigned)qp << 16) | (form8 << 24));
       if (lane == 0) {
         wv::lds_st32(ts + S_INFO + 32 * buf + 16, task);
         wv::lds_st32(ts + S_INFO + 32 * buf + 20, (unsigned)s);
@@ -1786,6 +1797,7 @@ WV void top_border(int ts, int g, int x, int par, int i) {
 // (left columns, line rings, tile borders), predicts and reconstructs the step's Intra8x8 macroblocks into the tiles
 // while BACK runs the Intra16x16 pass and the Intra4x4 chain on the others (macroblocks of one step never depend on each
 // other), and says so; BACK waits for that before it frees the record and writes the step out.
+template <bool WIDE>
 WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int ts) {
   const int lane0 = wv::lane_id();
   BAND_DIAG_BEGIN();
@@ -1812,9 +1824,19 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
     const bool mbA = x > 0;
     const int slot = x & 1;
     const int tile = tile_of(ts, g, x);
-    const int kind = (int)(wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g) & 3u);
+    const unsigned info = wv::lds_u32(ts + S_INFO + 32 * buf + 4 * g);
+    const int kind = (int)(info & 3u);
     PH(0);  // wait for the record
     if (wv::any(valid && kind == 1)) {
+      // the step's Intra8x8 residuals: the passes over the coefficients FRONT left in the record, then the residuals in their place
+      // (nothing here needs the step before: it runs while BACK writes that one out)
+      {
+        unsigned r8[8];
+        const unsigned form = (unsigned)wv::rfl((int)(info >> 24));
+        residual8x8_run<WIDE>(form, valid && kind == 1, lane, (int)((info >> 16) & 0xffu), ldsBase, ts, ts + S_RES + RES_BUF * buf, r8);
+        if (valid && kind == 1) residual8x8_store(form, lane, resBuf, r8);
+        wv::wave_sync();
+      }
       team_wait(ts + S_F8 + F8_WO, gstep);
       PH(1);  // wait for BACK's write-out of the step before
       if (i < 7 && kind == 1) top_border(ts, g, x, par, i);

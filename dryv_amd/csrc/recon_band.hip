@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64 * ((HAS_I8 || WIDE) ? 4 : band::WAVES_PER_W
 #endif
   if (role == 1) band::band_back<HAS_I8>(P, A, ldsBase, ts);
   else if (role == 0) band::band_front<HAS_I8, WIDE>(P, A, ldsBase, ts);
-  else if (HAS_I8 && role == 3) band::band_back8(P, A, ldsBase, ts);
+  else if (HAS_I8 && role == 3) band::band_back8<WIDE>(P, A, ldsBase, ts);
   else band::band_chroma<HAS_I8, WIDE>(P, A, ldsBase, ts);
 }
 

@@ -100,7 +100,8 @@ static void body() {
   const int role = wave_index() % waves_per_team(i8);  // FRONT / BACK / CHROMA (/ BACK8) of team t (each team has its own LDS here)
   const int ts = i8 ? T_END_I8 : T_END;
   if (role == 3) {
-    band_back8(g_P, g_A, 0, ts);
+    if (g_wide) band_back8<true>(g_P, g_A, 0, ts);
+    else band_back8<false>(g_P, g_A, 0, ts);
   } else if (role == 1) {
     if (i8) band_back<true>(g_P, g_A, 0, ts);
     else band_back<false>(g_P, g_A, 0, ts);
