@@ -236,6 +236,41 @@ def test_handoff_records_across_launches_and_layouts(recon_ctx):
         assert_parity(recon_ctx, fp, frames, mbs, co)
 
 
+@pytest.mark.parametrize("t8", [False, True], ids=["no8x8", "8x8"])
+def test_mode_records_are_never_served_stale(recon_ctx, t8):
+    """The one inter-workgroup hand-off that is a flag and not a data-tagged granule: a band's mode records (sc1 stores, drained,
+    then the band's progress word; the band below polls the word and reads the records with sc1 loads, no acquire fence --
+    DESIGN.md section 4.2 says which form of MI355X_MICROARCH.md that is and where it leaves the measured envelope: several
+    workgroups per CU). Directed at exactly that: ONE context, TWO batches of identical geometry -- so every record of one
+    launch sits at the address of the other's -- all Intra4x4 (Intra4x4 / Intra8x8 with the 8x8 transform) with different
+    seeds, so that the bottom-row modes of every band differ between the two; tiny pictures of several bands, so that a
+    launch's records are a few KB and hot in whatever cache served the launch before; sixteen launches alternating between
+    the two, queued back to back on the stream. A mode record served from the previous launch derives the row below from the
+    wrong neighbours: a wrong picture."""
+    import torch
+    W, H, frames = 6, 14, 3    # 4 bands (the last of 2 rows), 84 macroblocks: 2.6 KB of mode records per picture
+    fp = abi.make_frame_params(W, H, transform_8x8=t8)
+    batches = []
+    for seed in (9100, 9101):
+        mbs, co = synth.generate(fp, synth.config(i4x4=0.5 if t8 else 1.0, i8x8=0.5 if t8 else 0.0), seed, 0, frames)
+        st, want = oracle.reconstruct(fp, frames, mbs, co)
+        assert st == 0
+        batches.append((torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda(), torch.from_numpy(co).cuda(), want))
+    per = frames * W * H * 384
+    outs = [torch.zeros(per, dtype=torch.uint8, device="cuda") for _ in range(16)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            d_m, d_c, _ = batches[k & 1]
+            recon_ctx.submit_device_queued(fp, frames, d_m.data_ptr(), d_c.data_ptr(), o.data_ptr())
+        recon_ctx.sync()
+        for k, o in enumerate(outs):
+            assert np.array_equal(o.cpu().numpy(), batches[k & 1][2]), "launch %d of round %d" % (k, rep)
+
+
 def test_queued_device_submits(recon_ctx):
     """dryv_recon_submit_device_queued: several batches behind each other on the stream, one sync (what bench.py times).
     Three different batches of different sizes into buffers of their own; then a queue in which the middle batch has
