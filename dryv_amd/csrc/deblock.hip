@@ -34,13 +34,12 @@ int deblock_waves_per_block() { return DRYV_DEBLOCK_WAVES; }
 int deblock_blocks_per_cu() { return DRYV_DEBLOCK_WGS_PER_CU; }
 
 hipError_t deblock_launch(const deblock::DParams& P, const void* d_mbs, void* d_yuv, unsigned* d_status, void* d_workspace,
-                          int grid, unsigned gen, hipStream_t stream) {
+                          int grid, hipStream_t stream) {
   unsigned char* wsb = (unsigned char*)d_workspace;
   deblock::Args A;
   A.mbs = (const dryv_mb_desc*)d_mbs;
   A.yuv = (uint8_t*)d_yuv;
   A.status = d_status;
-  A.gen = gen;
   deblock::place_workspace(P, wsb, &A);
   const size_t ldsBytes = (size_t)deblock::T_END + (size_t)DRYV_DEBLOCK_WAVES * deblock::S_BYTES;
   hipLaunchKernelGGL(deblock_kernel, dim3(grid), dim3(64 * DRYV_DEBLOCK_WAVES), ldsBytes, stream, P, A);

@@ -16,13 +16,10 @@
 //     macroblock is final towards the left once its right neighbour's left edge has been filtered, and its bottom four
 //     rows only once the macroblock below has filtered its top edge: rows 0..11 are stored one step late by the row
 //     itself, rows 12..15 travel through an LDS ring to the row below (patched with columns 12..15 one step late) and are
-//     stored by it. Between bands they travel through a side buffer in the workspace as 8-byte granules that carry their own
-//     tag, {4 pixels, the launch's generation} (cdna_hip_programming.md Guideline 16, R2: the data is the flag; one aligned
-//     8-byte sc1 store, one 8-byte sc1 load -- as the reconstruction kernel's hand-off records): the producer neither waits
-//     for its stores nor publishes a progress word (round 3's form did both, once per step: a band's step then lasted as
-//     long as a write-through store takes to be acknowledged), the consumer requests a macroblock's granules a step ahead
-//     and polls only the lanes whose tag is not there. (A side buffer and not the picture, because the band below also
-//     WRITES the final values of those lines into the picture.)
+//     stored by it. Between bands they travel through a side buffer in the workspace (write-through stores, drained,
+//     then a progress word: MI355X_MICROARCH.md "valid forms"; a side buffer and not the picture, because the band below
+//     also WRITES the final values of those lines into the picture: a line it has written could be served stale from
+//     its own L2 when a later macroblock's bytes of the same line are handed over).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -40,9 +37,8 @@ struct Args {
   unsigned* status;        // bit 2 (value 4): a band gave up waiting (words 1..3: where)
   // per plane kind (0 luma, 1 chroma):
   unsigned* taskCounter[2];
-  unsigned long long* side[2];   // [frame][band][W][16]: 4 luma rows x 4 granules   /   [frame][band][W][8]: (Cb, Cr) x rows 6, 7 x 2 granules
-  unsigned gen;                  // the launch's generation: a granule is there when its tag is (never 0, never repeated over the
-                                 // life of the workspace, which is zeroed when it is (re)allocated or laid out anew)
+  unsigned* prog[2];       // [frame][band]: macroblocks of the band's last row whose bottom rows are in the side buffer
+  uint8_t* side[2];        // [frame][band][W][64]: 4 luma rows x 16   /   [frame][band][W][32]: Cb rows 6, 7 and Cr rows 6, 7 x 8
 };
 
 // per-workgroup tables
@@ -56,7 +52,7 @@ constexpr int S_RING = S_CTILE + 4 * 2 * 10 * CSTR;       // u8 [4][4 entries][4
 constexpr int S_RINGC = S_RING + 4 * 256;                 // u8 [4][4 entries][2][2 rows][8]
 constexpr int S_BYTES = (S_RINGC + 4 * 128 + 63) & ~63;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-constexpr int SIDE_Y = 16, SIDE_C = 8;   // granules per macroblock of a band's last row
+constexpr int SIDE_Y = 64, SIDE_C = 32;
 
 WV void build_tables(const DParams& P, int ldsBase, int tid, int nthreads) {
   for (int k = tid; k < 52; k += nthreads) {
@@ -164,8 +160,10 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
     uint8_t* const plane = A.yuv + (size_t)f * frameBytes;
     const dryv_mb_desc* const mbsF = A.mbs + (size_t)f * W * H;
     constexpr int SIDE_ENTRY = LUMA ? SIDE_Y : SIDE_C;
-    unsigned long long* const mySide = A.side[LUMA ? 0 : 1] + ((size_t)f * nBands + b) * (size_t)W * SIDE_ENTRY;
-    const unsigned long long* const upSide = mySide - (size_t)W * SIDE_ENTRY;
+    unsigned* const myProg = A.prog[LUMA ? 0 : 1] + (size_t)f * nBands + b;
+    const unsigned* const upProg = myProg - 1;
+    uint8_t* const mySide = A.side[LUMA ? 0 : 1] + ((size_t)f * nBands + b) * (size_t)W * SIDE_ENTRY;
+    const uint8_t* const upSide = mySide - (size_t)W * SIDE_ENTRY;
 
     const int lane = lane0;
     const int g = lane >> 4, i = lane & 15;
@@ -191,7 +189,12 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
     };
     prefetch(-2 * g);
     int qpLeft = 0;
-    unsigned long long granN = 0;   // this lane's granule of the band above's macroblock s + 1, requested during the previous step
+    unsigned upKnown = 0, flagV = 0;
+    bool flagPend = false, haveN = false;
+    u32x4 topYn = {0, 0, 0, 0};  // the band above's rows for the NEXT step, requested a step early when it is far enough ahead
+    u32x2 topCn = {0, 0};
+    bool linePend = false;
+    unsigned pubCount = 0;
 
     for (int s = 0; s < nSteps; s++) {
       const int x = s - 2 * g;
@@ -204,59 +207,88 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       const u32x4 curY = rowY;
       const u32x2 curC = rowC;
 
-      // ---- what the band above hands to row 0: lanes 0 .. SIDE_ENTRY - 1 hold one granule each of macroblock s (luma: row
-      // lane >> 2, dword lane & 3; chroma: plane lane >> 2, row (lane >> 1) & 1, dword lane & 1), requested a step ago; the lanes
-      // whose tag is not there yet poll (bounded: SPIN_LIMIT, reported as status bit 2 + where)
-      unsigned topV = 0;
-      if (hasAbove && s < W) {
-        const bool fl = lane < SIDE_ENTRY;
-        const unsigned long long* const rec = upSide + (size_t)s * SIDE_ENTRY + (fl ? lane : 0);
-        unsigned long long v = 0;
-        if (fl) v = s > 0 ? granN : wv::ld_sc1_64(rec);
+      // ---- fetch what the band above hands to row 0: its progress word is read one step ahead, and so are the rows themselves
+      // whenever it has got that far (the request then has a whole step to come back)
+      u32x4 topY = {0, 0, 0, 0};
+      u32x2 topC = {0, 0};
+      auto fetch_side = [&](int mb, u32x4& y, u32x2& c) {
+        const unsigned* e = (const unsigned*)(upSide + (size_t)mb * SIDE_ENTRY);
+        if (LUMA && lane < 4) {
+          y.x = wv::ld_sc1(e + 4 * lane);
+          y.y = wv::ld_sc1(e + 4 * lane + 1);
+          y.z = wv::ld_sc1(e + 4 * lane + 2);
+          y.w = wv::ld_sc1(e + 4 * lane + 3);
+        } else if (!LUMA && lane >= 4 && lane < 8) {
+          c.x = wv::ld_sc1(e + 2 * (lane - 4));
+          c.y = wv::ld_sc1(e + 2 * (lane - 4) + 1);
+        }
+      };
+      bool haveNext = false;
+      if (hasAbove && s < W) {  // row 0 is at macroblock s: the band above must have handed over macroblock s
+        if (flagPend) upKnown = max(upKnown, (unsigned)wv::rfl((int)flagV));
+        flagPend = false;
         unsigned spins = 0;
-        while (wv::any(fl && (unsigned)(v >> 32) != A.gen)) {
-          wv::sleep_short();
-          if (fl && (unsigned)(v >> 32) != A.gen) v = wv::ld_sc1_64(rec);
-          if (++spins > SPIN_LIMIT) {
-            if (lane == 0) {
-              wv::atomic_or(A.status, 4u);
-              A.status[1] = task;
-              A.status[2] = ((unsigned)s << 16) | (unsigned)(s + 1);
-              A.status[3] = (unsigned)(v >> 32);
+        while (upKnown < (unsigned)(s + 1)) {
+          const unsigned v = wv::ld_sc1(upProg);
+          upKnown = (unsigned)wv::rfl((int)v);
+          if (upKnown < (unsigned)(s + 1)) {
+            wv::sleep_short();
+            if (++spins > SPIN_LIMIT) {
+              if (lane == 0) {
+                wv::atomic_or(A.status, 4u);
+                A.status[1] = task;
+                A.status[2] = ((unsigned)s << 16) | (unsigned)(s + 1);
+                A.status[3] = upKnown;
+              }
+              upKnown = (unsigned)W;
             }
-            break;
           }
         }
-        topV = (unsigned)v;
-        if (fl && s + 1 < W) granN = wv::ld_sc1_64(rec + SIDE_ENTRY);
+        wv::compiler_fence();
+        if (haveN) {
+          topY = topYn;
+          topC = topCn;
+        } else {
+          fetch_side(s, topY, topC);
+        }
+        haveNext = s + 1 < W && upKnown >= (unsigned)(s + 2);
+        if (haveNext) fetch_side(s + 1, topYn, topCn);
+        if (upKnown < (unsigned)W) {
+          flagV = wv::ld_sc1(upProg);
+          flagPend = true;
+        }
       }
+      haveN = haveNext;
       // the next step's macroblock (its registers are free: curY / curC hold this step's)
       prefetch(x + 1);
 
       // ---- tile: the four (two) rows above this macroblock (its own rows go in after the vertical edges, straight from the
       // registers they were loaded into)
-      if (proc && mbB && g > 0) {
-        if (LUMA && i < 4) {
-          const int rs = ts + S_RING + 256 * (g - 1) + 64 * (x & 3) + 16 * i;
-          const u32x4 t = u32x4{wv::lds_u32(rs), wv::lds_u32(rs + 4), wv::lds_u32(rs + 8), wv::lds_u32(rs + 12)};
-          const int dt = tile + LSTR * i + 16 * slot;
-          wv::lds_st32(dt, t.x);
-          wv::lds_st32(dt + 4, t.y);
-          wv::lds_st32(dt + 8, t.z);
-          wv::lds_st32(dt + 12, t.w);
-        } else if (!LUMA && i >= 4 && i < 8) {
-          const int pl = (i - 4) >> 1, rw = (i - 4) & 1;
-          const int rs = ts + S_RINGC + 128 * (g - 1) + 32 * (x & 3) + 16 * pl + 8 * rw;
-          const u32x2 t = u32x2{wv::lds_u32(rs), wv::lds_u32(rs + 4)};
-          const int dt = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * pl + CSTR * rw + 8 * slot;
-          wv::lds_st32(dt, t.x);
-          wv::lds_st32(dt + 4, t.y);
+      if (proc) {
+        if (mbB) {
+          if (LUMA && i < 4) {
+            u32x4 t = topY;
+            if (g > 0) {
+              const int rs = ts + S_RING + 256 * (g - 1) + 64 * (x & 3) + 16 * i;
+              t = u32x4{wv::lds_u32(rs), wv::lds_u32(rs + 4), wv::lds_u32(rs + 8), wv::lds_u32(rs + 12)};
+            }
+            const int dt = tile + LSTR * i + 16 * slot;
+            wv::lds_st32(dt, t.x);
+            wv::lds_st32(dt + 4, t.y);
+            wv::lds_st32(dt + 8, t.z);
+            wv::lds_st32(dt + 12, t.w);
+          } else if (!LUMA && i >= 4 && i < 8) {
+            const int pl = (i - 4) >> 1, rw = (i - 4) & 1;
+            u32x2 t = topC;
+            if (g > 0) {
+              const int rs = ts + S_RINGC + 128 * (g - 1) + 32 * (x & 3) + 16 * pl + 8 * rw;
+              t = u32x2{wv::lds_u32(rs), wv::lds_u32(rs + 4)};
+            }
+            const int dt = ts + S_CTILE + 2 * 10 * CSTR * g + 10 * CSTR * pl + CSTR * rw + 8 * slot;
+            wv::lds_st32(dt, t.x);
+            wv::lds_st32(dt + 4, t.y);
+          }
         }
-      }
-      if (hasAbove && s < W && lane < SIDE_ENTRY) {   // (row 0 of the band: macroblock s, a granule's pixels per lane)
-        const int sl0 = s & 1;
-        if (LUMA) wv::lds_st32(ts + S_TILE + LSTR * (lane >> 2) + 16 * sl0 + 4 * (lane & 3), topV);
-        else wv::lds_st32(ts + S_CTILE + 10 * CSTR * (lane >> 2) + CSTR * ((lane >> 1) & 1) + 8 * sl0 + 4 * (lane & 1), topV);
       }
 
       // ---- vertical edges: lane = pixel row ----------------------------------------------------------------------------
@@ -374,33 +406,45 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       if (LUMA) {
         rowY.x = (unsigned)wv::opaque((int)rowY.x); rowY.y = (unsigned)wv::opaque((int)rowY.y);
         rowY.z = (unsigned)wv::opaque((int)rowY.z); rowY.w = (unsigned)wv::opaque((int)rowY.w);
+        topYn.x = (unsigned)wv::opaque((int)topYn.x); topYn.y = (unsigned)wv::opaque((int)topYn.y);
+        topYn.z = (unsigned)wv::opaque((int)topYn.z); topYn.w = (unsigned)wv::opaque((int)topYn.w);
       } else {
         rowC.x = (unsigned)wv::opaque((int)rowC.x); rowC.y = (unsigned)wv::opaque((int)rowC.y);
+        topCn.x = (unsigned)wv::opaque((int)topCn.x); topCn.y = (unsigned)wv::opaque((int)topCn.y);
       }
       dCur = (unsigned)wv::opaque((int)dCur);
       dTop = (unsigned)wv::opaque((int)dTop);
-      granN = (unsigned long long)(unsigned)wv::opaque((int)(unsigned)granN) | ((unsigned long long)(unsigned)wv::opaque((int)(unsigned)(granN >> 32)) << 32);
+      flagV = (unsigned)wv::opaque((int)flagV);
+      // ---- publish what the PREVIOUS step handed to the band below: its write-through stores have had this whole step to drain
+      if (linePend) {
+        wv::wait_vm(0);
+        if (lane == 0) wv::st_sc1(myProg, pubCount);
+        linePend = false;
+      }
       // ---- stores: macroblock x - 1 is final except for its bottom rows; the macroblock above is final ----------------
       if (fin) {
         const int xl = x - 1;
-        unsigned long long* const e = mySide + (size_t)xl * SIDE_ENTRY;
-        const unsigned long long tag = (unsigned long long)A.gen << 32;
+        unsigned* e = (unsigned*)(mySide + (size_t)xl * SIDE_ENTRY);
         const bool toBelow = hasBelow && g == gl;  // the band's last row: its bottom rows go to the band below through the side buffer
         if (LUMA) {
           if (i < 12 || lastRow) wv::st_g128(plane + (size_t)(16 * r + i) * pitchY + 16 * xl, vy);
           if (toBelow && i >= 12) {
-            wv::st_sc1_64(e + 4 * (i - 12), vy.x | tag);
-            wv::st_sc1_64(e + 4 * (i - 12) + 1, vy.y | tag);
-            wv::st_sc1_64(e + 4 * (i - 12) + 2, vy.z | tag);
-            wv::st_sc1_64(e + 4 * (i - 12) + 3, vy.w | tag);
+            wv::st_sc1(e + 4 * (i - 12), vy.x);
+            wv::st_sc1(e + 4 * (i - 12) + 1, vy.y);
+            wv::st_sc1(e + 4 * (i - 12) + 2, vy.z);
+            wv::st_sc1(e + 4 * (i - 12) + 3, vy.w);
           }
         } else {
           if (crow < 6 || lastRow) wv::st_g64(plane + (cpl ? offCr : offCb) + (size_t)(8 * r + crow) * pitchC + 8 * xl, vc);
           if (toBelow && crow >= 6) {
-            wv::st_sc1_64(e + 4 * cpl + 2 * (crow - 6), vc.x | tag);
-            wv::st_sc1_64(e + 4 * cpl + 2 * (crow - 6) + 1, vc.y | tag);
+            wv::st_sc1(e + 4 * cpl + 2 * (crow - 6), vc.x);
+            wv::st_sc1(e + 4 * cpl + 2 * (crow - 6) + 1, vc.y);
           }
         }
+      }
+      if (hasBelow && wv::any(fin && g == gl)) {
+        linePend = true;
+        pubCount = (unsigned)(s - 2 * gl);  // macroblocks 0 .. x - 1 of the last row are in the side buffer
       }
       if (topOut) {  // the macroblock above: its bottom four (two) rows are final now
         if (LUMA && i < 4) {
@@ -412,6 +456,10 @@ WV void deblock_wave(const DParams& P, const Args& A, const int ldsBase, const i
       }
       if (proc) qpLeft = qp;
       wv::wave_sync();
+    }
+    if (hasBelow) {
+      wv::wait_vm(0);
+      if (lane0 == 0) wv::st_sc1(myProg, (unsigned)W);
     }
   }
 }

@@ -40,19 +40,21 @@ inline int build_dparams(const dryv_frame_params* fp, const dryv_deblock_params*
   return DRYV_OK;
 }
 
-// Workspace: [luma task counter | chroma task counter (128 bytes apart) | pad to 256][luma side buffer][chroma side buffer].
-// The side buffers hold tagged 8-byte granules (deblock_kernel.h): they are zeroed when the workspace is (re)allocated or
-// laid out for other dimensions, never per launch -- a launch brings a generation of its own.
-inline size_t band_count(const DParams& P) { return (size_t)P.n_frames * ((size_t)(P.H + 3) / 4); }
-inline size_t reset_bytes(const DParams&) { return 256; }   // leading part a launch needs zeroed: the task counters
-inline size_t side_bytes(const DParams& P) { return band_count(P) * P.W * (16 + 8) * 8; }
-inline size_t workspace_bytes(const DParams& P) { return reset_bytes(P) + side_bytes(P); }
+// Workspace: [luma task counter | chroma task counter (128 bytes apart) | pad to 256][luma progress words][chroma progress
+// words | pad to 256][luma side buffer][chroma side buffer]
+inline size_t prog_words(const DParams& P) { return (size_t)P.n_frames * ((size_t)(P.H + 3) / 4); }
+inline size_t reset_bytes(const DParams& P) {  // leading part a launch needs zeroed: task counters, progress words
+  return 256 + ((2 * prog_words(P) * 4 + 255) & ~(size_t)255);
+}
+inline size_t workspace_bytes(const DParams& P) { return reset_bytes(P) + prog_words(P) * P.W * (64 + 32); }
 template <class ARGS>
 inline void place_workspace(const DParams& P, unsigned char* ws, ARGS* A) {
   A->taskCounter[0] = (unsigned*)ws;
   A->taskCounter[1] = (unsigned*)(ws + 128);
-  A->side[0] = (unsigned long long*)(ws + reset_bytes(P));
-  A->side[1] = A->side[0] + band_count(P) * P.W * 16;
+  A->prog[0] = (unsigned*)(ws + 256);
+  A->prog[1] = A->prog[0] + prog_words(P);
+  A->side[0] = ws + reset_bytes(P);
+  A->side[1] = A->side[0] + prog_words(P) * P.W * 64;
 }
 
 }  // namespace deblock

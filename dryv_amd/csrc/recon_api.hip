@@ -38,9 +38,7 @@ struct dryv_recon_ctx {
   void* d_yuv = nullptr;
   size_t cap_mbs = 0, cap_coeffs = 0, cap_yuv = 0;
   void* d_pack = nullptr;        // output stage (dryv_recon_wait_packed): grow-only
-  void* d_dbwork = nullptr;      // deblocking workspace (task counters, side buffers): grow-only
-  const void* db_ws = nullptr;   // ... and what its side buffers were last zeroed for
-  int db_W = 0, db_H = 0, db_frames = 0;
+  void* d_dbwork = nullptr;      // deblocking workspace (task counter, progress words, side buffer): grow-only
   size_t cap_dbwork = 0;
   size_t cap_pack = 0;
   dryv_frame_params pending_fp;  // the parameters of the host-path batch in flight
@@ -94,7 +92,6 @@ int ensure(dryv_recon_ctx* ctx, void** p, size_t* cap, size_t need) {
   if (*cap >= need) return DRYV_OK;
   if (*p) (void)hipFree(*p);
   if (p == &ctx->d_work) ctx->hand_ws = nullptr;   // (a new workspace: its hand-off records are not zeroed yet)
-  if (p == &ctx->d_dbwork) ctx->db_ws = nullptr;   // (... its side buffers)
   *p = nullptr;
   *cap = 0;
   hipError_t e = hipMalloc(p, need);
@@ -130,10 +127,7 @@ int prepare_workspace(dryv_recon_ctx* ctx, const KParams& P, unsigned* gen) {
     ctx->hand_W = P.W;
     ctx->hand_H = P.H;
     ctx->hand_frames = P.n_frames;
-    if (g == 0) {
-      g = 1;
-      ctx->db_ws = nullptr;   // (the deblocking workspace's granules count generations on the same counter)
-    }
+    if (g == 0) g = 1;
   }
   ctx->launch_gen = g;
   *gen = g;
@@ -430,28 +424,13 @@ int dryv_recon_deblock_device(dryv_recon_ctx* ctx, const dryv_frame_params* fp, 
   if ((st = ensure(ctx, &ctx->d_dbwork, &ctx->cap_dbwork, dryv::deblock::workspace_bytes(P))) != DRYV_OK) return st;
   hipError_t e = hipMemsetAsync(ctx->d_dbwork, 0, dryv::deblock::reset_bytes(P), ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream);
-  // the side buffers' granules carry the launch's generation: zeroed when the workspace is new or laid out for other
-  // dimensions (or the generation counter wraps), never per launch
-  unsigned gen = ctx->launch_gen + 1;
-  if (ctx->db_ws != ctx->d_dbwork || ctx->db_W != P.W || ctx->db_H != P.H || ctx->db_frames != P.n_frames || gen == 0) {
-    if (e == hipSuccess) e = hipMemsetAsync((unsigned char*)ctx->d_dbwork + dryv::deblock::reset_bytes(P), 0, dryv::deblock::side_bytes(P), ctx->stream);
-    ctx->db_ws = ctx->d_dbwork;
-    ctx->db_W = P.W;
-    ctx->db_H = P.H;
-    ctx->db_frames = P.n_frames;
-    if (gen == 0) {
-      gen = 1;
-      ctx->hand_ws = nullptr;   // (the reconstruction workspace's hand-off records count generations on the same counter)
-    }
-  }
-  ctx->launch_gen = gen;
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(deblock workspace)");
   const long long tasks = 2ll * P.n_frames * ((P.H + 3) / 4);  // a luma and a chroma task per band
   const int wpb = dryv::deblock_waves_per_block();
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::deblock_blocks_per_cu();
   grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
   if ((e = hipEventRecord(ctx->ev_start, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  if ((e = dryv::deblock_launch(P, d_mbs, d_yuv, ctx->d_status, ctx->d_dbwork, (int)grid, gen, ctx->stream)) != hipSuccess)
+  if ((e = dryv::deblock_launch(P, d_mbs, d_yuv, ctx->d_status, ctx->d_dbwork, (int)grid, ctx->stream)) != hipSuccess)
     return fail(ctx, e, "deblock_kernel launch");
   if ((e = hipEventRecord(ctx->ev_stop, ctx->stream)) != hipSuccess) return fail(ctx, e, "hipEventRecord");
   if ((e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)

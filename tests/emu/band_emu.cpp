@@ -227,7 +227,6 @@ extern "C" int dryv_emu_deblock(const dryv_frame_params* fp, const dryv_deblock_
   g_DA.yuv = yuv;
   g_DA.status = status;
   dryv::deblock::place_workspace(g_DP, ws.data(), &g_DA);
-  g_DA.gen = 0x5EEDu;   // (the side buffers hold 0xC3 bytes: no granule carries this tag before it is written)
   wv::g_body = deblock_body;
   const int ldsBytes = dryv::deblock::T_END + dryv::deblock::S_BYTES;
   std::vector<std::unique_ptr<wv::Wave>> waves;
@@ -241,7 +240,7 @@ extern "C" int dryv_emu_deblock(const dryv_frame_params* fp, const dryv_deblock_
     wv::g_emu_cur = &waves.back()->st;
     dryv::deblock::build_tables(g_DP, 0, 0, 1);
   }
-  const size_t nGran = dryv::deblock::side_bytes(g_DP) / 8;   // (progress = claimed tasks + hand-off granules written)
+  const size_t nProg = 2 * (size_t)n_frames * ((g_DP.H + 3) / 4);
   int live = n_waves;
   unsigned long long idle_rounds = 0;
   for (int k = 0; live > 0; k++) {
@@ -249,7 +248,7 @@ extern "C" int dryv_emu_deblock(const dryv_frame_params* fp, const dryv_deblock_
     if (w->finished) continue;
     auto progress = [&]() {
       unsigned long long t = *g_DA.taskCounter[0] + *g_DA.taskCounter[1];
-      for (size_t q = 0; q < nGran; q++) t += (unsigned)(g_DA.side[0][q] >> 32) == g_DA.gen ? 1u : 0u;
+      for (size_t q = 0; q < nProg; q++) t += g_DA.prog[0][q];
       return t;
     };
     const unsigned long long before = progress();
