@@ -207,6 +207,9 @@ WV int ringy(int ts, int g, int e, int par) {
 #ifndef DRYV_BAND_FRONT_LEAD
 #define DRYV_BAND_FRONT_LEAD(hasI8) ((hasI8) ? 2 : -1)
 #endif
+#ifndef DRYV_BAND_MODES_ACQUIRE
+#define DRYV_BAND_MODES_ACQUIRE 1
+#endif
 #ifndef DRYV_BAND_CHROMA_TRAIL
 #define DRYV_BAND_CHROMA_TRAIL 4
 #endif
@@ -1000,8 +1003,15 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
     // batch only when it gets there -- the pre-passes of a picture's bands overlap instead of queueing up behind each other
     // (pictures of three batches or more; narrower ones publish once: 120 macroblocks wide, the second publication and its
     // drain cost 1 % and overlap nothing; 240 wide, four batches: -1.7 %)
-    if (G.hasAbove && g == 0)
+    if (G.hasAbove && g == 0) {
+      const unsigned before = upKnownM;
       upKnownM = poll_progress(upProgM, upProgM, upKnownM, (unsigned)(perBatch ? min(x0 + 64, W) : W), (unsigned)W, A.status, task, -1, lane);
+      // (the records behind this flag are read with sc1 loads, which MI355X_MICROARCH.md measured in
+      // place of an acquire for one workgroup per CU only -- this kernel runs 2 to 5: so the consumer's form is the guide's
+      // "always" one, ONE relaxed poll, ONE agent acquire, the wait for it, then the loads; once per band, or per batch of
+      // wide pictures: not measurable in the launch (tools/ab_inproc.py: 300 x 1080p -1.1 %, 100 x 4K +0.1 %))
+      if (DRYV_BAND_MODES_ACQUIRE && upKnownM != before) wv::acquire_agent();
+    }
     if (it == 0) TLM(task, 1, TNOW());
     const int x = x0 + lane;
     const bool valid = x < W;

@@ -179,6 +179,11 @@ WV void sleep_long() { __builtin_amdgcn_s_sleep(32); }
 #endif
 WV void sleep_team() { __builtin_amdgcn_s_sleep(DRYV_TEAM_SLEEP); }  // between two polls of the partner wave's LDS flag
 WV void compiler_fence() { asm volatile("" ::: "memory"); }
+// agent-scope acquire: invalidates this CU's L1 (buffer_inv sc1) and waits for it
+WV void acquire_agent() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // wave priority for the SIMD's issue arbiter (s_setprio 0..3)
 template <int P>
 WV void setprio() { __builtin_amdgcn_s_setprio(P); }

@@ -200,6 +200,7 @@ WV void sleep_short() { emu_barrier("@sleep"); }
 WV void sleep_long() { emu_barrier("@sleep"); }
 WV void sleep_team() { emu_barrier("@sleep"); }
 WV void compiler_fence() {}
+WV void acquire_agent() {}
 template <int P>
 WV void setprio() {}
 WV int opaque(int v) { return v; }
