@@ -2,7 +2,7 @@
 # copies the evidence tools/gpu_final.sh left in gpurun_out/ into profiles/<round>/ and refreshes
 # profiles/hbm_traffic.json. Usage: tools/collect_profiles.sh r02
 set -e
-R=${1:-r03}; F=gpurun_out/final; P=profiles/$R; mkdir -p $P
+R=${1:-r04}; F=gpurun_out/final; P=profiles/$R; mkdir -p $P
 cp $F/timeline.txt $P/band_timeline.txt
 cp $F/bench_default.json $P/bench_default_line.json
 for c in c2 c3; do

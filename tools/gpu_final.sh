@@ -9,11 +9,11 @@ timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.er
 echo "bench ok"
 timeout -k 10 600 python bench.py --workload C3_4k_intra_8x8 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err || { echo "bench c3 failed"; tail -5 $O/bench_c3.err; exit 1; }
 echo "bench c3 ok"
-DRYV_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_2ranks_gloo_one_gpu.json 2> $O/bench_2ranks.err || { echo "2-rank rehearsal failed"; tail -5 $O/bench_2ranks.err; exit 1; }
+DRYV_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 10 --warmup 3 2> $O/bench_2ranks.err | grep '^{' > $O/bench_2ranks_gloo_one_gpu.json || { echo "2-rank rehearsal failed"; tail -5 $O/bench_2ranks.err; exit 1; }
 echo "2-rank launcher rehearsal ok"
-timeout -k 10 600 bash tools/profile_round.sh r03_c2 > $O/profile_c2.log 2>&1 || { echo "profile c2 failed"; tail -5 $O/profile_c2.log; exit 1; }
+timeout -k 10 600 bash tools/profile_round.sh r04_c2 > $O/profile_c2.log 2>&1 || { echo "profile c2 failed"; tail -5 $O/profile_c2.log; exit 1; }
 echo "profile c2 ok"
-timeout -k 10 600 bash tools/profile_round.sh r03_c3 C3_4k_intra_8x8 > $O/profile_c3.log 2>&1 || { echo "profile c3 failed"; tail -5 $O/profile_c3.log; exit 1; }
+timeout -k 10 600 bash tools/profile_round.sh r04_c3 C3_4k_intra_8x8 > $O/profile_c3.log 2>&1 || { echo "profile c3 failed"; tail -5 $O/profile_c3.log; exit 1; }
 echo "profile c3 ok"
 timeout -k 10 300 python tools/band_phases.py 1 300 > $O/phases.txt 2>&1 || { echo "phases failed"; tail -5 $O/phases.txt; exit 1; }
 timeout -k 10 300 python tools/band_timeline.py 300 > $O/timeline.txt 2>&1 || { echo "timeline failed"; tail -5 $O/timeline.txt; exit 1; }
@@ -24,6 +24,7 @@ timeout -k 10 300 python tools/host_path_rate.py --frames 100 --reps 4 --out $O/
 timeout -k 10 200 python tools/pack_rate.py 300 --out $O/pack_rate.json > $O/pack_rate.log 2>&1 || { echo "pack rate failed"; tail -5 $O/pack_rate.log; exit 1; }
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate tools/micro/valu_rate.hip && timeout -k 5 120 /tmp/valu_rate > $O/valu_rate.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mem_pattern tools/micro/mem_pattern.hip && timeout -k 5 120 /tmp/mem_pattern > $O/mem_pattern.txt 2>&1
+timeout -k 10 300 python tools/gpu_fuzz.py 120 801 > $O/gpu_fuzz.txt 2>&1 || { echo "gpu fuzz failed"; tail -5 $O/gpu_fuzz.txt; exit 1; }
 timeout -k 10 300 python tools/deblock_rate.py 300 --out $O/deblock_rate.json > $O/deblock_rate.log 2>&1 || { echo "deblock rate failed"; tail -5 $O/deblock_rate.log; exit 1; }
 timeout -k 10 600 python tools/stream_rate.py 300 --out $O/stream_rate.json > $O/stream_rate.log 2>&1 || { echo "stream rate failed"; tail -5 $O/stream_rate.log; exit 1; }
 echo "all ok"

@@ -1,4 +1,5 @@
-R=$GRAFT_REPO_ROOT
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/ea; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for so in $R/dryv_amd/lib/var/*.so; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # analysis only (GPU box): LDS bank conflicts and wave-cycle shares of the libraries in dryv_amd/lib/var/
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 WL=${WL:-C2_1080p_intra_4x4}   # WL=C3_4k_intra_8x8 for the 4K batch
 OUT=$R/gpurun_out/lds; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # analysis only (GPU box): address-translation and L1 <-> L2 request counters of the libraries in dryv_amd/lib/var/
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 WL=${WL:-C2_1080p_intra_4x4}
 OUT=$R/gpurun_out/mem; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # analysis only (GPU box): for every library in dryv_amd/lib/var/ (or those named): kernel time alternating over ROUNDS rounds
 # (bench.py, unprofiled) and one PMC pass (SQ_INSTS_VALU / SALU / LDS / BRANCH per macroblock). -> gpurun_out/var/summary.txt
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 ROUNDS=${ROUNDS:-2}
 WL=${WL:-C2_1080p_intra_4x4}   # WL=C3_4k_intra_8x8 for the 4K batch
 OUT=$R/gpurun_out/var
