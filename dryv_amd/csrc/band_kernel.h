@@ -249,6 +249,8 @@ constexpr int WAVES_PER_WG = WAVES_PER_TEAM * TEAMS_PER_WG;
 #endif
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // polls of a hand-off record / progress word (about a second) before a band gives up
 constexpr unsigned TASK_END = 0xFFFFFFFFu;
+constexpr int PROG_SHIFT = 11;                      // (a row has at most 1024 macroblocks)
+constexpr unsigned PROG_GEN_MASK = 0x1FFFFFu;       // the host never hands out a generation whose low 21 bits are 0
 
 struct Args {
   const dryv_mb_desc* mbs;
@@ -259,9 +261,11 @@ struct Args {
   unsigned* handoff;    // [frame][band that has a band below][mb][16]: the bottom lines of the band's last row, in eight 8-byte
                         // granules {4 pixels, tag}: four of luma, two of Cb, two of Cr. tag = gen: a granule is there when its tag is
   unsigned gen;         // the launch's generation (never 0, never repeated over the life of the workspace)
-  unsigned* progM;      // [frame][band]: W once the band's mode records (below) are visible
+  unsigned* progM;      // [frame][band]: (gen & PROG_GEN_MASK) << PROG_SHIFT | the macroblocks of the band's last row whose mode
+                        // records (below) are visible; a word of another launch counts as 0: nothing is zeroed per launch
   unsigned* rowModes;   // [mb][8]: the mode record of every macroblock (MREC_*), written by the band's mode pre-pass
   unsigned* taskCounter;
+  unsigned taskBase;    // ... which keeps counting from launch to launch: this launch's tasks are its values from taskBase on
   unsigned long long* profile;  // DRYV_BAND_PROFILE builds only
   int waveBase;                 // (global index of the workgroup's first wave, for the same)
   unsigned batchSeq;            // position of this launch in the host's queue of batches (status[4])
@@ -926,11 +930,12 @@ WV unsigned long long await_granules(const unsigned long long* rec, unsigned lon
 
 // Polls progress words of the band above until they reach `need` (bounded: see SPIN_LIMIT). Lanes 0..31 read pa,
 // lanes 32..63 pb (the same word twice where a wave follows only one).
-WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned known, unsigned need, unsigned W, unsigned* status,
+WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned tag, unsigned known, unsigned need, unsigned W, unsigned* status,
                           unsigned task, int s, int lane) {
   unsigned spins = 0;
   while (known < need) {
-    const unsigned v = wv::ld_sc1((const unsigned*)((const uint8_t*)pa + (lane < 32 ? 0u : 4u * (unsigned)(pb - pa))));  // (all lanes: see the claim in band_front)
+    const unsigned w = wv::ld_sc1((const unsigned*)((const uint8_t*)pa + (lane < 32 ? 0u : 4u * (unsigned)(pb - pa))));  // (all lanes: see the claim in band_front)
+    const unsigned v = (w >> PROG_SHIFT) == tag ? w & ((1u << PROG_SHIFT) - 1u) : 0u;   // (a word of an earlier launch: nothing yet)
     known = min((unsigned)wv::rfl((int)v), (unsigned)wv::rdlane((int)v, 32));
     if (known < need) {
       wv::sleep_short();
@@ -1005,7 +1010,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
     // drain cost 1 % and overlap nothing; 240 wide, four batches: -1.7 %)
     if (G.hasAbove && g == 0) {
       const unsigned before = upKnownM;
-      upKnownM = poll_progress(upProgM, upProgM, upKnownM, (unsigned)(perBatch ? min(x0 + 64, W) : W), (unsigned)W, A.status, task, -1, lane);
+      upKnownM = poll_progress(upProgM, upProgM, A.gen & PROG_GEN_MASK, upKnownM, (unsigned)(perBatch ? min(x0 + 64, W) : W), (unsigned)W, A.status, task, -1, lane);
       // (the records behind this flag are read with sc1 loads, which MI355X_MICROARCH.md measured in
       // place of an acquire for one workgroup per CU only -- this kernel runs 2 to 5: so the consumer's form is the guide's
       // "always" one, ONE relaxed poll, ONE agent acquire, the wait for it, then the loads; once per band, or per batch of
@@ -1160,7 +1165,7 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
     // count is W: FRONT of this band's team waits for the LDS flag, the band below for this word)
     if (G.hasBelow && g == nR - 1 && (perBatch || it == nIter - 1)) {
       wv::wait_vm(0);
-      if (lane == 0) wv::st_sc1(myProgM, (unsigned)min(x0 + 64, W));
+      if (lane == 0) wv::st_sc1(myProgM, ((A.gen & PROG_GEN_MASK) << PROG_SHIFT) | (unsigned)min(x0 + 64, W));
     }
   }
   wv::wait_vm(0);
@@ -1192,7 +1197,7 @@ WV void band_front(const KParams& P, const Args& A, const int ldsBase, const int
   // loop, after which the readfirstlane executes under a partial exec mask and returns another lane's value.
   auto claim_push = [&](unsigned q) -> unsigned {
     const unsigned tsk = wv::atomic_add_task(A.taskCounter, lane0 == 0 ? 1u : 0u);
-    unsigned t = (unsigned)wv::rfl((int)tsk);
+    unsigned t = (unsigned)wv::rfl((int)tsk) - A.taskBase;
     if (t >= totalTasks) t = TASK_END;
     if (q >= 4) team_wait_ge(ts + S_FLAGS + F_TAILC, q - 3);
     if (lane0 == 0) wv::lds_st32(ts + S_FLAGS + F_TASKS + 4 * (int)(q & 3u), t);

@@ -53,6 +53,7 @@ struct dryv_recon_ctx {
   // the hand-off records between bands carry the launch's generation as their tag: they are zeroed when the workspace is
   // (re)allocated or laid out for other picture dimensions / batch sizes, never per launch
   unsigned launch_gen = 0;
+  unsigned task_base = 0;          // what the workspace's task counter stands at (it is never reset between launches)
   const void* hand_ws = nullptr;   // the workspace and the layout the records were last zeroed for
   int hand_W = 0, hand_H = 0, hand_frames = 0;
   int num_cus = 256;
@@ -113,12 +114,17 @@ size_t workspace_bytes(const KParams& P) {
 
 // The per-launch part of the workspace (task counter, progress words) zeroed on the stream; the hand-off records zeroed if
 // this is another workspace or another layout than the last launch's. Returns the launch's generation in *gen.
-int prepare_workspace(dryv_recon_ctx* ctx, const KParams& P, unsigned* gen) {
-  hipError_t e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
+// Nothing in the workspace is reset per launch: the task counter keeps counting (a launch's tasks are its values from
+// task_base on), progress words and hand-off records carry the launch's generation. Everything is zeroed when the workspace
+// is new or laid out for other dimensions, or when the generation's low 21 bits (the progress words' tag) come round.
+int prepare_workspace(dryv_recon_ctx* ctx, const KParams& P, unsigned* gen, unsigned* task_base) {
+  hipError_t e;
   unsigned g = ctx->launch_gen + 1;
+  if ((g & 0x1FFFFFu) == 0u) g++;   // (never a tag of 0; g == 0 is caught by the wrap below as well)
   const bool other = ctx->hand_ws != ctx->d_work || ctx->hand_W != P.W || ctx->hand_H != P.H || ctx->hand_frames != P.n_frames;
-  if (other || g == 0) {
+  if (other || (g >> 21) != (ctx->launch_gen >> 21)) {
+    e = hipMemsetAsync(ctx->d_work, 0, dryv::band_reset_bytes(P), ctx->stream);
+    if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(workspace)");
     if (dryv::band_handoff_bytes(P) != 0) {
       e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_handoff_offset(P), 0, dryv::band_handoff_bytes(P), ctx->stream);
       if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(hand-off records)");
@@ -127,10 +133,12 @@ int prepare_workspace(dryv_recon_ctx* ctx, const KParams& P, unsigned* gen) {
     ctx->hand_W = P.W;
     ctx->hand_H = P.H;
     ctx->hand_frames = P.n_frames;
+    ctx->task_base = 0;
     if (g == 0) g = 1;
   }
   ctx->launch_gen = g;
   *gen = g;
+  *task_base = ctx->task_base;
   return DRYV_OK;
 }
 
@@ -148,21 +156,19 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, wide);
   if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
   if (grid < 1) grid = 1;
-  unsigned gen = 0;
-  if (int st = prepare_workspace(ctx, P, &gen)) return st;
+  unsigned gen = 0, task_base = 0;
+  if (int st = prepare_workspace(ctx, P, &gen, &task_base)) return st;
 #if defined(DRYV_BAND_PROFILE) || defined(DRYV_BAND_TRACE) || defined(DRYV_BAND_TIMELINE)
   e = hipMemsetAsync((unsigned char*)ctx->d_work + dryv::band_profile_offset(P), 0, (size_t)65536 * 16 * 8 + (size_t)65536 * 32 * 2, ctx->stream);
   if (e != hipSuccess) return fail(ctx, e, "hipMemsetAsync(profile)");
 #endif
   next_events(ctx);
-  e = hipEventRecord(ctx->ev_start, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, (unsigned)ctx->queued.size(), gen, ctx->stream);
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, wide, (unsigned)ctx->queued.size(), gen, task_base, ctx->stream,
+                        ctx->ev_start, ctx->ev_stop);
   if (e != hipSuccess) return fail(ctx, e, "band_kernel launch");
-  e = hipEventRecord(ctx->ev_stop, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipEventRecord");
-  e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, e, "hipMemcpyAsync(status)");
+  ctx->task_base += dryv::band_claims_per_launch(P, (int)grid, wide);
+  // (the status words are fetched where the host waits -- finish() --, once per wait: a 32-byte copy behind every launch of a
+  // queue is a stream operation of its own between two kernels)
   ctx->timed = true;
   return DRYV_OK;
 }
@@ -177,16 +183,24 @@ int launch_chunk(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const
   const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, false);
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, false);
   grid = std::max(1ll, std::min(grid, (tasks + wpb - 1) / wpb));
-  unsigned gen = 0;
-  if (int st = prepare_workspace(ctx, P, &gen)) return st;
-  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, 0u, gen, ctx->stream);
-  return e == hipSuccess ? DRYV_OK : fail(ctx, e, "band_kernel launch");
+  unsigned gen = 0, task_base = 0;
+  if (int st = prepare_workspace(ctx, P, &gen, &task_base)) return st;
+  e = dryv::band_launch(P, d_mbs, d_coeffs, d_yuv, ctx->d_status, ctx->d_work, (int)grid, false, 0u, gen, task_base, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, e, "band_kernel launch");
+  ctx->task_base += dryv::band_claims_per_launch(P, (int)grid, false);
+  return DRYV_OK;
 }
 
 // Waits for the launch in flight. A batch the fast band kernel flagged as needing 64-bit arithmetic is run again with
 // the wide build (same buffers; the caller's inputs are still valid: they must be until wait/sync returns).
+// the device's status words behind everything queued so far, then the wait
+hipError_t sync_with_status(dryv_recon_ctx* ctx) {
+  hipError_t e = hipMemcpyAsync(ctx->h_status, ctx->d_status, 32, hipMemcpyDeviceToHost, ctx->stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+
 int finish(dryv_recon_ctx* ctx) {
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = sync_with_status(ctx);
   if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
   if (ctx->piped) {
     ctx->piped = false;
@@ -202,7 +216,7 @@ int finish(dryv_recon_ctx* ctx) {
       int st = launch_band(ctx, P, ctx->d_mbs, ctx->d_coeffs, ctx->d_yuv, true);
       if (st != DRYV_OK) return st;
       e = hipMemcpyAsync(ctx->piped_out, ctx->d_yuv, (size_t)P.n_frames * P.W * P.H * 384, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) e = sync_with_status(ctx);
       if (e != hipSuccess) return fail(ctx, e, "wide re-run");
     }
   } else
@@ -230,7 +244,7 @@ int finish(dryv_recon_ctx* ctx) {
       st = launch_band(ctx, ctx->last_P, ctx->last_mbs, ctx->last_coeffs, ctx->last_yuv, true);
     }
     if (st != DRYV_OK) return st;
-    e = hipStreamSynchronize(ctx->stream);
+    e = sync_with_status(ctx);
     if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
     if ((keep & 4u) && !(ctx->h_status[0] & 4u)) {
       ctx->h_status[1] = keep1;

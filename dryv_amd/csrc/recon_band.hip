@@ -1,5 +1,6 @@
 // recon_band.hip — device entry point and launch of the band kernel (band_kernel.h) for gfx950.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "band_kernel.h"
 #include "band_launch.h"
@@ -92,9 +93,13 @@ size_t band_handoff_bytes(const KParams& P) {
 size_t band_profile_offset(const KParams& P) { return band_handoff_offset(P) + band_handoff_bytes(P); }
 size_t band_workspace_bytes(const KParams& P) { return band_profile_offset(P); }
 
+unsigned band_claims_per_launch(const KParams& P, int grid, bool wide) {
+  return (unsigned)P.n_frames * (unsigned)((P.H + 3) / 4) + (unsigned)grid * (unsigned)band_teams_per_block(P.transform8x8 != 0, wide);
+}
+
 // wide: the build whose residual passes fall back to 64-bit arithmetic (see band_kernel.h, residual_pass).
 hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs, void* d_yuv, unsigned* d_status,
-                       void* d_workspace, int grid, bool wide, unsigned batch_seq, unsigned gen, hipStream_t stream) {
+                       void* d_workspace, int grid, bool wide, unsigned batch_seq, unsigned gen, unsigned task_base, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   unsigned char* wsb = (unsigned char*)d_workspace;
   band::Args A;
   A.mbs = (const dryv_mb_desc*)d_mbs;
@@ -105,6 +110,7 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
   A.progM = (unsigned*)(wsb + 256);
   A.handoff = (unsigned*)(wsb + band_handoff_offset(P));
   A.gen = gen;
+  A.taskBase = task_base;
   A.rowModes = (unsigned*)(wsb + 256 + band_prog_bytes(P));
   A.profile = nullptr;
   A.waveBase = 0;
@@ -122,10 +128,12 @@ hipError_t band_launch(const KParams& P, const void* d_mbs, const void* d_coeffs
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
   }
-  if (i8 && wide) hipLaunchKernelGGL((band_kernel<true, true>), g, b, ldsBytes, stream, P, A);
-  else if (i8) hipLaunchKernelGGL((band_kernel<true, false>), g, b, ldsBytes, stream, P, A);
-  else if (wide) hipLaunchKernelGGL((band_kernel<false, true>), g, b, ldsBytes, stream, P, A);
-  else hipLaunchKernelGGL((band_kernel<false, false>), g, b, ldsBytes, stream, P, A);
+  // (the events, where given, take the dispatch's own start and end: no marker packets of their own in the stream, which cost a
+  // queue of launches several microseconds per launch between its kernels)
+  if (i8 && wide) hipExtLaunchKernelGGL((band_kernel<true, true>), g, b, (unsigned)ldsBytes, stream, ev_start, ev_stop, 0, P, A);
+  else if (i8) hipExtLaunchKernelGGL((band_kernel<true, false>), g, b, (unsigned)ldsBytes, stream, ev_start, ev_stop, 0, P, A);
+  else if (wide) hipExtLaunchKernelGGL((band_kernel<false, true>), g, b, (unsigned)ldsBytes, stream, ev_start, ev_stop, 0, P, A);
+  else hipExtLaunchKernelGGL((band_kernel<false, false>), g, b, (unsigned)ldsBytes, stream, ev_start, ev_stop, 0, P, A);
   return hipGetLastError();
 }
 

@@ -138,12 +138,12 @@ extern "C" int dryv_emu_reconstruct(const dryv_frame_params* fp, uint32_t n_fram
   std::vector<unsigned> hand((size_t)n_frames * (nBands > 1 ? nBands - 1 : 0) * g_P.W * dryv::band::HAND_WORDS + 1, 0u);
   // like the host API: the fast build first; if it flags a block beyond int32 (status bit 1), the batch again with the wide build
   unsigned status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned counter = 0;
   for (int pass = 0; pass < 2; pass++) {
-    unsigned counter = 0;
     memset(status, 0, sizeof status);
-    std::fill(prog.begin(), prog.end(), 0u);
     g_wide = pass == 1;
-    g_A = dryv::band::Args{mbs, coeffs, yuv, status, hand.data(), (unsigned)(pass + 1), prog.data(), modes.data(), &counter, nullptr, 0, 0u};
+    // (like the host API, nothing is reset between the two launches: the counter keeps counting, the words keep their tags)
+    g_A = dryv::band::Args{mbs, coeffs, yuv, status, hand.data(), (unsigned)(pass + 1), prog.data(), modes.data(), &counter, counter, nullptr, 0, 0u};
     wv::g_body = body;
     std::vector<std::unique_ptr<wv::Wave>> waves;
     const int teamBytes = dryv::band::team_bytes(g_P.transform8x8 != 0, true);   // (one size for both passes: the wide build's)
