@@ -186,11 +186,12 @@ int dryv_recon_deblock_device(dryv_recon_ctx *ctx, const dryv_frame_params *fp, 
 int dryv_recon_wait_filtered(dryv_recon_ctx *ctx, const dryv_deblock_params *dp, const dryv_output_desc *od, uint8_t *out,
                              size_t out_bytes);
 
-/* Device time of the most recent reconstruction kernel launch, from HIP events recorded on the
- * context's own stream immediately around the launch. Valid after wait/sync. */
+/* Device time of the most recent reconstruction kernel launch, from a pair of HIP events on the context's own stream that
+ * take the dispatch's own start and end (hipExtLaunchKernelGGL: what rocprofv3 --kernel-trace reports for the kernel).
+ * Valid after wait/sync. */
 int dryv_recon_last_kernel_ms(dryv_recon_ctx *ctx, float *ms);
 /* Average / minimum / maximum device time of the n_last most recent reconstruction kernel launches (at most 64 are
- * remembered; every launch is bracketed by an event pair of its own, so queued launches are timed one by one). Any of the
+ * remembered; every launch has an event pair of its own, so queued launches are timed one by one). Any of the
  * three pointers may be NULL. Valid after wait/sync. */
 int dryv_recon_kernel_ms_stats(dryv_recon_ctx *ctx, uint32_t n_last, float *avg_ms, float *min_ms, float *max_ms);
 /* Diagnostics of the 64-bit fallback: how many times a sync / wait found a batch flagged by the fast kernel build (a
