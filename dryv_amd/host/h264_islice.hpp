@@ -993,8 +993,17 @@ struct Stream {
     for (int& v : spsById) v = -1;
     for (int& v : ppsById) v = -1;
   }
-  const Sps& sps_of(const Nal& nal) const { return spsAll[(size_t)nal.sps]; }
-  const Pps& pps_of(const Nal& nal) const { return ppsAll[(size_t)nal.pps]; }
+  // (a coded slice whose parameter sets were not sent is recorded with -1 and refused only when it is asked for: a stream whose
+  // inter slices use a picture parameter set that arrives late, or not at all, still yields its intra pictures)
+  const Sps& sps_of(const Nal& nal) const {
+    if (nal.pps < 0) fail("coded slice refers to a picture parameter set that was not sent");
+    if (nal.sps < 0) fail("picture parameter set refers to a sequence parameter set that was not sent");
+    return spsAll[(size_t)nal.sps];
+  }
+  const Pps& pps_of(const Nal& nal) const {
+    if (nal.pps < 0) fail("coded slice refers to a picture parameter set that was not sent");
+    return ppsAll[(size_t)nal.pps];
+  }
 };
 
 inline void take_nal(Stream& S, const uint8_t* p, size_t n) {
@@ -1021,10 +1030,8 @@ inline void take_nal(Stream& S, const uint8_t* p, size_t n) {
     r.ue();
     const unsigned pid = r.ue();
     const int pi = pid < 256 ? S.ppsById[pid] : -1;
-    if (pi < 0) fail("coded slice refers to a picture parameter set that was not sent");
-    const int si = S.spsById[S.ppsAll[(size_t)pi].sps_id];
-    if (si < 0) fail("picture parameter set refers to a sequence parameter set that was not sent");
-    S.slices.push_back(Stream::Nal{p, n, si, pi});
+    const int si = pi < 0 ? -1 : S.spsById[S.ppsAll[(size_t)pi].sps_id];
+    S.slices.push_back(Stream::Nal{p, n, si, pi});   // (pi / si < 0: refused when the slice is asked for, Stream::sps_of)
   }
 }
 

@@ -139,6 +139,25 @@ def test_all_intra_stream_round_trip():
     assert np.array_equal(co1, co[:54])
 
 
+def test_inter_slice_with_a_missing_parameter_set_does_not_cost_the_intra_pictures():
+    """An inter slice that names a picture parameter set which was never sent (arrives late, was lost, is not supported) is
+    skipped like every inter slice: the stream's intra pictures still parse. An intra picture that names one is refused --
+    when it is asked for."""
+    fp = abi.make_frame_params(5, 4)
+    mbs, co = synth.generate(fp, synth.config(i4x4=0.6), 616, 0, 2)
+    stream = bytes(h264.encode_stream(fp, 2, mbs, co, slice_qp=int(mbs["qp"][0])))
+    # a P slice, first_mb_in_slice 0, slice_type 0, pic_parameter_set_id 7 (ue: 1, 1, 0001000), then the stop bit
+    stray = b"\x00\x00\x00\x01\x41\xc4\x40"
+    k = stream.rfind(b"\x00\x00\x00\x01")            # in front of the second IDR slice
+    fp2, n2, mbs2, co2, info = h264.parse_all_islices(stream[:k] + stray + stream[k:])
+    assert n2 == 2 and info["skipped"] == 1 and np.array_equal(co2, co)
+    # the same stray unit as an IDR I slice (slice_type 7: ue 0001000; pps 7): asked for, refused
+    bad = b"\x00\x00\x00\x01\x65" + bytes([0b10001000, 0b00010001, 0b00000000])
+    with pytest.raises(h264.H264Error) as e:
+        h264.parse_all_islices(stream[:k] + bad)
+    assert "parameter set" in str(e.value)
+
+
 def test_real_mp4_intra_pictures_among_inter_ones():
     """realshort.mp4 is an ordinary IPB stream: sample positions come from stco / stsc / stsz, the intra pictures are
     parsed (each must end at its terminating bin), the inter pictures are counted and skipped."""
