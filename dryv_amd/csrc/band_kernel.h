@@ -88,15 +88,22 @@ constexpr int T_T4W = 3968;   // u32 [8][17][4] the block chain's prediction tab
 constexpr int T4W_PAIR = 272;  // a pixel pair's 16 entries + 16: the pairs' entries of one row on different banks
 constexpr int T_END = 6144;
 constexpr int T_LS8 = T_END;          // u16 [6][64]    LevelScale8x8, raster order (HAS_I8 only, like the next two)
-constexpr int T_T8 = T_LS8 + 768;     // u8  [9][64]    Intra8x8 table [mode][y*8+x]: byte offset of the sample in S_E8 (4 * position + which of E1 / F / G)
-constexpr int T_ZZ8 = T_T8 + 576;     // u8  [64]       8x8 list index -> 2 * raster position
+// Intra8x8 prediction (BACK8), per (table row, lane): lane (py, half) of a macroblock's sixteen predicts pixels 4 * half .. + 3 of row
+// py. Rows 0..8 = the modes, T8R_ZERO = quirk Q4's zero prediction (band_modes puts it in the mode record). A pixel is (the sum of
+// four bytes of the block's filtered edge + 2) >> 2, as in the Intra4x4 chain: (a, b, b, c), (a, a, b, b) or (a, a, a, a); the
+// bytes of a pixel PAIR lie in one aligned 8-byte window of the edge (tests/test_abi.py::test_prediction_tables_fit_aligned_windows).
+constexpr int T_T8S = T_LS8 + 768;    // u32 [10][4 + pad]  the four pixels' byte selectors (v_perm_b32) on their pair's window; a row every T8S_ROW
+constexpr int T8S_ROW = 272;          //                    (16 lanes x 16 + 16: the row groups of a wave, on different rows, on different banks)
+constexpr int T_T8O = T_T8S + 10 * T8S_ROW;   // u32 [10][16]  byte offset of the first pair's window in the edge | the second pair's << 16
+constexpr int T8R_ZERO = 9;
+constexpr int T_ZZ8 = T_T8O + 640;    // u8  [64]       8x8 list index -> 2 * raster position
 // the packed 16-bit form of the 8x8 residual (residual8x8_pk16): a lane works on rows 2p (low halves) and 2p + 1 (high halves)
 constexpr int T_LS8P = T_ZZ8 + 64;    // u32 [6][4][8]  LevelScale8x8 of (row 2p, column j) | (row 2p + 1, column j) << 16
 constexpr int T_ZZ8P = T_LS8P + 768;  // u8  [64]       8x8 list index -> byte offset of (row, column) in the pair-interleaved block:
                                       //                32 * (row >> 1) + 4 * column + 2 * (row & 1)
 constexpr int T_THR8P = T_ZZ8P + 64;  // u16 [52]       per qp: the largest sum of |coefficients| of an 8x8 block for which the packed form is
                                       //                exact (0: none)
-constexpr int T_END_I8 = T_THR8P + 128;
+constexpr int T_END_I8 = (T_THR8P + 128 + 63) & ~63;
 static_assert(T_END % 64 == 0 && T_END_I8 % 64 == 0, "table layout");
 
 // The block chain's table rows (T_T4W; a mode record holds 16 x the row): the nine Intra4x4 modes of 8.3.1.2 by number
@@ -171,20 +178,24 @@ constexpr int S_BYTES = (S_EDGE + 4 * E_ROW + 4 * E_SLOT + 63) & ~63;   // (+ 4 
 // eight of a 32-lane group on ONE bank); 8-byte aligned: the passes read it with ds_read_b64)
 constexpr int C8_BLK = 136, C8_MB = 4 * C8_BLK;
 static_assert(C8_MB == RES_ROW, "an Intra8x8 macroblock's coefficients take its residuals' place in the record");
-constexpr int S_E8 = S_BYTES;           // [4][128]  BACK8: the filtered edge of the current 8x8 block: 25 dwords E1 | F << 8 | G << 16 (L7..L0, TL,
-                                       //           T0..T15), then E1 once more as bytes for the DC sums (L7..L0 at 112, T0..T7 at 120)
-constexpr int S_F8 = S_E8 + 512;       // u32 [16]  flags between BACK and BACK8: b8Done (BACK8 -> BACK: Intra8x8 macroblocks of step n - 1 are in
+constexpr int S_E8 = S_BYTES;           // u8 [4][32]  BACK8: the filtered edge E1 of the current 8x8 block, a row group every 32 bytes: L7..L0, TL, T0..T15
+constexpr int S_F8 = S_E8 + 128;       // u32 [16]  flags between BACK and BACK8: b8Done (BACK8 -> BACK: Intra8x8 macroblocks of step n - 1 are in
                                        //           the tiles), woDone (BACK -> BACK8: the write-out of step n - 1 is through)
 constexpr int F8_DONE = 0, F8_WO = 4;
 constexpr int G8_BLK = 144, G8_MB = 4 * G8_BLK;
-constexpr int S_MREC_I8 = S_F8 + 64;   // [64][32]  (the mode pre-pass's staging area, as S_MREC below, in the builds with the 8x8 transform)
-constexpr int S_G8 = S_MREC_I8 + 2048; // BACK8: row-pass output. 32-bit passes: T [4][2 blk8][8][8] (T: 4 bytes; 8 in the WIDE build, whose teams
+#ifndef DRYV_BAND_MREC_I8_BYTES
+#define DRYV_BAND_MREC_I8_BYTES 1024
+#endif
+constexpr int S_MREC_I8 = S_F8 + 64;   // [32][32]  (the mode pre-pass's staging area, as S_MREC below, in the builds with the 8x8 transform: half an
+                                       //           iteration's records at a time -- five of these workgroups have to fit a CU's LDS)
+constexpr int S_G8 = S_MREC_I8 + DRYV_BAND_MREC_I8_BYTES; // BACK8: row-pass output. 32-bit passes: T [4][2 blk8][8][8] (T: 4 bytes; 8 in the WIDE build, whose teams
                                        //           are that much larger); packed form: i16 [4][4 blk8][8][8] with G8_BLK / G8_MB strides, the four
                                        //           column pairs of row r rotated by r >> 1 (rows written and columns read without conflicts)
 // builds without it append instead:
 constexpr int S_MREC = S_BYTES;        // [64][32]  the wave that derives the modes: the mode records of a pre-pass iteration, on their way to memory
                                        //           as whole lines
 constexpr int mrec_off(bool hasI8) { return hasI8 ? S_MREC_I8 : S_MREC; }
+constexpr int mrec_bytes(bool hasI8) { return hasI8 ? DRYV_BAND_MREC_I8_BYTES : 2048; }
 constexpr int team_bytes(bool hasI8, bool wide) { return hasI8 ? S_G8 + (wide ? 4096 : 4 * G8_MB) : S_BYTES + 2048; }
 static_assert(S_EDGE % 16 == 0 && S_TILE % 64 == 0 && S_STC % 16 == 0, "scratch layout");
 // luma ring entry (16 bytes) of macroblock e of the row above row g. Row 0's ring is written by FRONT, which runs up to
@@ -330,7 +341,7 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
     // entry of (pixel pair p, table row m). P.t4 names a sample by its index j on the line [L3 L2 L1 L0 | corner | T0..T7]
     // (byte E_L3 + j of the block's edge array) and says whether the pixel is E[j], the 3-tap or the 2-tap value there: as
     // four bytes whose sum + 2 >> 2 is the pixel -- (a, b, b, c), (a, a, b, b), (a, a, a, a). The bytes of both pixels of a
-    // pair lie inside one aligned 8-byte window of the edge array for every row (checked on the host: tests/test_abi.py).
+    // pair lie inside one aligned 8-byte window of the edge array for every row (tests/test_abi.py::test_prediction_tables_fit_aligned_windows).
     const int p = k >> 4, m = k & 15;
     const int y = p >> 1;
     int by[2][4];
@@ -363,10 +374,31 @@ WV void build_tables(const KParams& P, int ldsBase, int tid, int nthreads, bool 
   }
   if (hasI8) {
     for (int k = tid; k < 384; k += nthreads) wv::lds_st16(ldsBase + T_LS8 + 2 * k, P.ls8[k]);
-    for (int k = tid; k < 576; k += nthreads) {
-      // index on the edge | which of E1 / F / G << 5 -> byte offset in BACK8's edge record (S_E8): a dword per sample
-      const int e = P.t8[k];
-      wv::lds_st8(ldsBase + T_T8 + k, (unsigned)(4 * (e & 31) + (e >> 5)));
+    for (int k = tid; k < 160; k += nthreads) {
+      // entry of (table row m, lane i). P.t8 names a sample by its index j on the filtered edge [L7..L0 | corner | T0..T15]
+      // (byte j of the block's edge array, S_E8) and says whether the pixel is E1[j], the 3-tap or the 2-tap value there
+      const int m = k >> 4, i = k & 15, y = i >> 1, x0 = 4 * (i & 1);
+      const bool zero = m == T8R_ZERO || m == 2;   // (DC: computed in the step)
+      unsigned sel[4], off[2] = {0u, 0u};
+      for (int pr = 0; pr < 2; pr++) {
+        int by[2][4], lo = 31;
+        for (int e = 0; e < 2; e++) {
+          const int en = zero ? 0 : P.t8[m * 64 + y * 8 + x0 + 2 * pr + e], j = en & 31, sl = en >> 5;
+          const int ja = sl == 1 ? j - 1 : j, jb = sl == 2 ? j + 1 : j, jc = sl == 1 ? j + 1 : j;
+          by[e][0] = min(max(ja, 0), 24);
+          by[e][1] = by[e][2] = min(max(jb, 0), 24);
+          by[e][3] = min(max(jc, 0), 24);
+          for (int q = 0; q < 4; q++) lo = min(lo, by[e][q]);
+        }
+        off[pr] = zero ? 0u : (unsigned)(lo & ~3);
+        for (int e = 0; e < 2; e++) {
+          unsigned v = 0;
+          for (int q = 0; q < 4; q++) v |= (zero ? 0x0cu : (unsigned)((by[e][q] - (int)off[pr]) & 7)) << (8 * q);
+          sel[2 * pr + e] = v;
+        }
+      }
+      wv::lds_st128(ldsBase + T_T8S + T8S_ROW * m + 16 * i, u32x4{sel[0], sel[1], sel[2], sel[3]});
+      wv::lds_st32(ldsBase + T_T8O + 64 * m + 4 * i, off[0] | (off[1] << 16));
     }
     for (int k = tid; k < 64; k += nthreads) wv::lds_st8(ldsBase + T_ZZ8 + P.zz8i[k], (unsigned)(2 * k));
     for (int k = tid; k < 192; k += nthreads) {
@@ -1143,21 +1175,54 @@ WV void band_modes(const KParams& P, const Args& A, const BandGeo& G, const unsi
         w0 = w1 = w2 = w3 = w4 = 0x10101010u * (unsigned)r16;
         dcMask = 0u;
       }
-      if (HAS_I8 && is8) w0 = ((unsigned)M[0] << 4) | ((unsigned)M[2] << 12) | ((unsigned)M[8] << 20) | ((unsigned)M[10] << 28);
+      if (HAS_I8 && wv::any(is8)) {
+        // an Intra8x8 macroblock: the table rows of its four blocks (T_T8S), x 16 like the others
+        int R[4] = {M[0], M[2], M[8], M[10]};
+        if (!rowTop || x0 == 0) {
+          // picture edges only: quirk Q4 as above (a directional mode without its samples: zero prediction)
+#pragma unroll
+          for (int b8 = 0; b8 < 4; b8++) {
+            const bool topAv = (b8 >> 1) > 0 || rowTop, leftAv = (b8 & 1) > 0 || !xIs0;
+            const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | ((topAv && leftAv) ? 4 : 0);
+            const int req = (int)((0x217771021ull >> (4 * R[b8])) & 7ull);
+            if ((req & ~have) != 0) R[b8] = T8R_ZERO;
+          }
+        }
+        if (is8) w0 = ((unsigned)R[0] << 4) | ((unsigned)R[1] << 12) | ((unsigned)R[2] << 20) | ((unsigned)R[3] << 28);
+      }
       {
         // The 64 records of the iteration are 2 KB of contiguous memory: through LDS, so that each of the two store
         // instructions writes whole lines -- lane by lane (16 of every 32 bytes per instruction) every write-through store
         // reaches memory as a partial line of its own: 1.4 M write requests more per 300 pictures, and 3 % of the launch
         const int stg = ts + mrec_off(HAS_I8);
         unsigned* rec0 = recF + (size_t)MREC_WORDS * (unsigned)((G.r0 + g) * W + x0);   // the batch's first record
-        wv::lds_st128(stg + 32 * lane, u32x4{w0, w1, w2, w3});
-        wv::lds_st128(stg + 32 * lane + 16, u32x4{w4, word0, dcMask, bottom});
-        wv::wave_sync();
-        // lane l: 16-byte chunks l and 64 + l of the batch (chunk c = half c & 1 of its record c >> 1)
-        const u32x4 va = wv::lds_u128(stg + 16 * lane), vb = wv::lds_u128(stg + 1024 + 16 * lane);
         unsigned* const dst = rec0 + 4 * lane;
-        if (x0 + (lane >> 1) < W) wv::st_g128_sc1(dst, va);
-        if (x0 + 32 + (lane >> 1) < W) wv::st_g128_sc1(dst + 256, vb);
+        // lane l: 16-byte chunks l and 64 + l of the batch (chunk c = half c & 1 of its record c >> 1)
+        if (mrec_bytes(HAS_I8) >= 2048) {
+          wv::lds_st128(stg + 32 * lane, u32x4{w0, w1, w2, w3});
+          wv::lds_st128(stg + 32 * lane + 16, u32x4{w4, word0, dcMask, bottom});
+          wv::wave_sync();
+          const u32x4 va = wv::lds_u128(stg + 16 * lane), vb = wv::lds_u128(stg + 1024 + 16 * lane);
+          if (x0 + (lane >> 1) < W) wv::st_g128_sc1(dst, va);
+          if (x0 + 32 + (lane >> 1) < W) wv::st_g128_sc1(dst + 256, vb);
+        } else {
+          // (a staging area of 1 KB: the records of lanes 0..31, then those of lanes 32..63; measures the same)
+          if (lane < 32) {
+            wv::lds_st128(stg + 32 * lane, u32x4{w0, w1, w2, w3});
+            wv::lds_st128(stg + 32 * lane + 16, u32x4{w4, word0, dcMask, bottom});
+          }
+          wv::wave_sync();
+          const u32x4 va = wv::lds_u128(stg + 16 * lane);
+          wv::wave_sync();
+          if (lane >= 32) {
+            wv::lds_st128(stg + 32 * (lane - 32), u32x4{w0, w1, w2, w3});
+            wv::lds_st128(stg + 32 * (lane - 32) + 16, u32x4{w4, word0, dcMask, bottom});
+          }
+          wv::wave_sync();
+          const u32x4 vb = wv::lds_u128(stg + 16 * lane);
+          if (x0 + (lane >> 1) < W) wv::st_g128_sc1(dst, va);
+          if (x0 + 32 + (lane >> 1) < W) wv::st_g128_sc1(dst + 256, vb);
+        }
       }
     }
     wv::wave_sync();  // (the records' staging area; lane 63's right columns: the next batch's macroblock A)
@@ -1858,31 +1923,30 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
       wv::wave_sync();
       // ================= luma, Intra8x8 (8.3.2, pred8x8.rs:152-696): four serial blocks ============================
       // The 16 lanes of a macroblock first build the block's filtered edge E1[0..24] = L7..L0, TL, T0..T15 (8.3.2.2.1,
-      // pred8x8.rs:222-288, incl. quirk Q1), two samples per lane with the neighbours exchanged by DPP, together with the
-      // 3-tap F and 2-tap G of the filtered samples; then every lane predicts four pixels of one row from the per-(mode,
-      // pixel) table (index on the edge, which of E1 / F / G), adds the residual and stores them into the tile.
+      // pred8x8.rs:222-288, incl. quirk Q1), two samples per lane with the neighbours exchanged by DPP, as bytes in LDS; then
+      // every lane predicts four pixels of one row the way the Intra4x4 chain does: per pixel pair an aligned 8-byte window of
+      // the edge, per pixel a byte selector on it and (sum of the four bytes + 2) >> 2 (T_T8S / T_T8O: by table row = mode, or
+      // quirk Q4's zero row, which band_modes has put in the mode record), adds the residual and stores them into the tile.
       {
         const bool mine = valid && kind == 1;
-        const int e8 = ts + S_E8 + 128 * g;
+        const int e8 = ts + S_E8 + 32 * g;
         const unsigned modes4 = wv::lds_u32(ts + S_MSEQ + 96 * buf + 24 * g);
         const bool mbC = mbB && (x + 1 < P.W);
         const int py = i >> 1, x0 = 4 * (i & 1);
-        // the four blocks' table entries (mode, pixel) and residuals depend on nothing the chain below produces: requested
-        // up front, so that a block's serial part is two LDS round trips (edge samples, filtered edge), not three
-        unsigned te4s[4];
+        // the four blocks' residuals depend on nothing the chain below produces: requested up front
         u32x2 rrs[4];
 #pragma unroll
-        for (int b8 = 0; b8 < 4; b8++) {
-          const int m8 = min((int)((modes4 >> (8 * b8 + 4)) & 0xfu), 8);
-          te4s[b8] = wv::lds_u32(ldsBase + T_T8 + 64 * m8 + 8 * py + x0);
+        for (int b8 = 0; b8 < 4; b8++)
           rrs[b8] = wv::lds_u64(resBuf + RES_ROW * g + 32 * (4 * (2 * (b8 >> 1) + (py >> 2)) + 2 * (b8 & 1) + (x0 >> 2)) + 8 * (py & 3));
-        }
 #pragma unroll
         for (int b8 = 0; b8 < 4; b8++) {
           const int bx = b8 & 1, by = b8 >> 1;
           const bool topAv = by > 0 || mbB, leftAv = bx > 0 || mbA, tlAv = topAv && leftAv;
           const bool trAv = b8 == 0 ? mbB : b8 == 1 ? mbC : b8 == 2;
-          const int mode = min((int)((modes4 >> (8 * b8 + 4)) & 0xfu), 8);
+          const int row = min((int)((modes4 >> (8 * b8 + 4)) & 0xfu), T8R_ZERO);
+          // the lane's table entry (it does not depend on the edge: on its way while the edge is built)
+          const u32x4 sel = wv::lds_u128(ldsBase + T_T8S + T8S_ROW * row + 16 * i);
+          const unsigned offs = wv::lds_u32(ldsBase + T_T8O + 64 * row + 4 * i);
           const int org8 = tile + TILE_STRIDE * (8 * by) + 8 + 16 * slot + 8 * bx;  // row y = -1, x = 0 of the block
           // raw edge samples k = i and k = i + 16 (top-right replaced by T7 when unavailable)
           auto eaddr = [&](int k) -> int {
@@ -1903,38 +1967,25 @@ WV void band_back8(const KParams& P, const Args& A, const int ldsBase, const int
           if (i == 9 && !tlAv) lfLo = -1;  // Q1: p[-1,-1] = -1 enters the x = 0 filter tap
           if (i == 7 && !tlAv) rtLo = lo;
           const int e1Lo = (lfLo + 2 * lo + rtLo + 2) >> 2, e1Hi = (lfHi + 2 * hi + rtHi + 2) >> 2;
-          const int elLo = wv::dpp<DPP_ROW_SHR(1)>(e1Lo, e1Lo);
-          const int erLo = wv::dpp<DPP_ROW_SHL(1)>(wv::dppx<DPP_ROW_ROR(15)>(e1Hi), e1Lo);
-          const int elHi = wv::dpp<DPP_ROW_SHR(1)>(wv::dppx<DPP_ROW_ROR(1)>(e1Lo), e1Hi);
-          int erHi = wv::dpp<DPP_ROW_SHL(1)>(e1Hi, e1Hi);
-          if (i >= 8) erHi = e1Hi;
-          // one dword per edge sample k: E1 | F << 8 | G << 16 (a table entry is the byte's offset: 4 k + which); E1 once
-          // more as bytes for the DC sums (L7..L0 at 112, T0..T7 at 120: two aligned dwords each)
-          wv::lds_st32(e8 + 4 * i, (unsigned)e1Lo | (((unsigned)(elLo + 2 * e1Lo + erLo + 2) >> 2) << 8) | (((unsigned)(e1Lo + erLo + 1) >> 1) << 16));
-          if (i != 8) wv::lds_st8(e8 + 112 + (i < 8 ? i : i - 1), (unsigned)e1Lo);
-          if (i <= 8) {
-            wv::lds_st32(e8 + 4 * (i + 16), (unsigned)e1Hi | (((unsigned)(elHi + 2 * e1Hi + erHi + 2) >> 2) << 8) | (((unsigned)(e1Hi + erHi + 1) >> 1) << 16));
-            if (i == 0) wv::lds_st8(e8 + 127, (unsigned)e1Hi);   // (T7 is sample 16)
-          }
+          wv::lds_st8(e8 + i, (unsigned)e1Lo);
+          if (i <= 8) wv::lds_st8(e8 + 16 + i, (unsigned)e1Hi);
           wv::wave_sync();
           // four pixels of row py: x0 .. x0 + 3
-          const unsigned te4 = te4s[b8];
-          unsigned pr[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) pr[q] = wv::lds_u8(e8 + (int)((te4 >> (8 * q)) & 0xffu));
-          {
-            const int have = (topAv ? 1 : 0) | (leftAv ? 2 : 0) | (tlAv ? 4 : 0);
-            const int req = (int)((0x217771021ull >> (4 * mode)) & 7ull);
-            if ((req & ~have) != 0) pr[0] = pr[1] = pr[2] = pr[3] = 0;   // quirk Q4
-            if (mode == 2) {  // DC (pred8x8.rs:350-394)
-              const int sumL = (int)wv::sad4(wv::lds_u32(e8 + 112)) + (int)wv::sad4(wv::lds_u32(e8 + 116));
-              const int sumT = (int)wv::sad4(wv::lds_u32(e8 + 120)) + (int)wv::sad4(wv::lds_u32(e8 + 124));
-              const int dc = (topAv && leftAv) ? (sumT + sumL + 8) >> 4 : leftAv ? (sumL + 4) >> 3 : topAv ? (sumT + 4) >> 3 : 128;
-              pr[0] = pr[1] = pr[2] = pr[3] = (unsigned)dc;
-            }
+          // (a window is 4-byte aligned: two dword reads, which the compiler issues as one ds_read2_b32)
+          const int qa = e8 + (int)(offs & 0xffffu), qb = e8 + (int)(offs >> 16);
+          const unsigned waL = wv::lds_u32(qa), waH = wv::lds_u32(qa + 4), wbL = wv::lds_u32(qb), wbH = wv::lds_u32(qb + 4);
+          unsigned p01 = wv::pk_lshr2(wv::sum4_hi(wv::perm(waH, waL, sel.y), wv::sum4(wv::perm(waH, waL, sel.x), 0x00020002u)));
+          unsigned p23 = wv::pk_lshr2(wv::sum4_hi(wv::perm(wbH, wbL, sel.w), wv::sum4(wv::perm(wbH, wbL, sel.z), 0x00020002u)));
+          if (row == 2) {  // DC (pred8x8.rs:350-394): L7..L0 are bytes 0..7 of the edge, T0..T7 bytes 9..16
+            const u32x2 l = wv::lds_u64(e8);
+            const unsigned t8 = wv::lds_u32(e8 + 8), t12 = wv::lds_u32(e8 + 12), t16 = wv::lds_u32(e8 + 16);
+            const int sumL = (int)wv::dot4(l.x, 0x01010101u, wv::dot4(l.y, 0x01010101u, 0u));
+            const int sumT = (int)wv::dot4(t8, 0x01010100u, wv::dot4(t12, 0x01010101u, wv::dot4(t16, 0x00000001u, 0u)));
+            const int dc = (topAv && leftAv) ? (sumT + sumL + 8) >> 4 : leftAv ? (sumL + 4) >> 3 : topAv ? (sumT + 4) >> 3 : 128;
+            p01 = p23 = (unsigned)dc * 0x10001u;
           }
           const u32x2 rr = rrs[b8];
-          const unsigned o = recon_row(pr[0] | (pr[1] << 16), pr[2] | (pr[3] << 16), rr.x, rr.y);
+          const unsigned o = recon_row(p01, p23, rr.x, rr.y);
           if (mine) wv::lds_st32(org8 + TILE_STRIDE * (py + 1) + x0, o);
           wv::wave_sync();
         }

@@ -8,6 +8,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 
 from dryv_amd import _build, abi
 
@@ -138,3 +139,43 @@ def test_output_stage_geometry_and_validation():
                 abi.make_output_desc(7, (0, 0, 0, 0))):
         assert lib.dryv_recon_output_bytes(C.byref(fp), C.byref(bad)) == 0
     assert C.sizeof(abi.OutputDesc) == 12
+
+
+def _pred_table(n):
+    """recon_params.h build_pred_table, restated: per (mode, x, y) which of E / F (3 taps) / G (2 taps) at which index of the
+    edge line [left column bottom..top | corner | top row + top right]."""
+    E, F, G = 0, 1, 2
+    C, T0, L0 = n, n + 1, n - 1
+    t = {}
+    for y in range(n):
+        for x in range(n):
+            t[0, x, y] = (E, T0 + x)
+            t[1, x, y] = (E, L0 - y)
+            t[3, x, y] = (F, T0 + 1 + x + y)
+            t[4, x, y] = (F, C + x - y)
+            z, k = 2 * x - y, x - (y >> 1)
+            t[5, x, y] = ((F if z & 1 else G), C + k) if z >= 0 else (F, C) if z == -1 else (F, T0 - y + 2 * x)
+            z, k = 2 * y - x, y - (x >> 1)
+            t[6, x, y] = ((F, C - k) if z & 1 else (G, L0 - k)) if z >= 0 else (F, C) if z == -1 else (F, L0 + x - 2 * y)
+            t[7, x, y] = (F, T0 + 1 + x + (y >> 1)) if y & 1 else (G, T0 + x + (y >> 1))
+            z, k, zmax = x + 2 * y, y + (x >> 1), 2 * n - 3
+            t[8, x, y] = ((F if z & 1 else G), n - 2 - k) if z < zmax else (F, 0) if z == zmax else (E, 0)
+    return t
+
+
+@pytest.mark.parametrize("n,jmax", [(4, 12), (8, 24)])
+def test_prediction_tables_fit_aligned_windows(n, jmax):
+    """The block chain (Intra4x4) and BACK8 (Intra8x8) read a pixel PAIR's reference bytes from ONE 4-byte-aligned 8-byte window of
+    the edge line and pick them with v_perm_b32 (band_kernel.h build_tables: T_T4W, T_T8S / T_T8O): every pair's taps, as the
+    table builders derive them from build_pred_table, must lie within 8 bytes of the aligned start."""
+    E, F, G = 0, 1, 2
+    t = _pred_table(n)
+    for mode in (0, 1, 3, 4, 5, 6, 7, 8):
+        for y in range(n):
+            for pair in range(n // 2):
+                taps = []
+                for x in (2 * pair, 2 * pair + 1):
+                    s, j = t[mode, x, y]
+                    taps += [min(max(v, 0), jmax) for v in ((j - 1 if s == F else j), (j + 1 if s == G else j), (j + 1 if s == F else j))]
+                off = min(taps) & ~3
+                assert max(taps) - off <= 7, (n, mode, y, pair, taps)
