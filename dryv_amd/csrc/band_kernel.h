@@ -999,9 +999,9 @@ WV unsigned poll_progress(const unsigned* pa, const unsigned* pb, unsigned tag, 
 //     right column changes (then every lane has seen its final inputs). A change only travels on when it flips a
 //     comparison, so two or three passes are the rule; the bound is one pass per lane.
 //   * Out: one 32-byte mode record per macroblock in global memory (workspace), in exactly the form the steps consume:
-//       bytes 0..19  the Intra4x4 chain's table rows x 8, [block half][chain round] (= S_MSEQ's layout; rows 9..11 =
+//       bytes 0..19  the Intra4x4 chain's table rows x 16, [block half][chain round] (= S_MSEQ's layout; rows 9..11 =
 //                    zero prediction of quirk Q4 / modes 3, 7 without a top-right block); an Intra8x8 macroblock:
-//                    bytes 0..3 = its four modes x 8
+//                    bytes 0..3 = the table rows of its four blocks x 16 (T_T8S: the modes, or T8R_ZERO for quirk Q4)
 //       word 5       the record's first word (kind, Intra16x16 / chroma modes, qp), checked: an unsupported record is
 //                    reported here (status bit 0) and reads as kind 3 / qp 0 from then on
 //       word 6       chain rounds of the macroblock that have a DC-predicted block (bit t)
