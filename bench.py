@@ -157,7 +157,8 @@ def secondary_line(name, device, dev_index, steps, warmup, cpu_frames):
         kernel_ms = run(steps)
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) * 1e3 / steps
-    verified = True
+        piped = pipelined_line(ctx, fp, frames, d_mbs, d_coeffs, d_out, frames * per, steps, warmup)
+    verified = piped["outputs_equal_primary_run"]
     for fidx in sorted({0, frames - 1}):
         st, want = oracle.reconstruct(fp, 1, mbs[fidx * per:(fidx + 1) * per], coeffs[fidx * per:(fidx + 1) * per])
         got = d_out[fidx * per * 384:(fidx + 1) * per * 384].cpu().numpy()
@@ -173,9 +174,48 @@ def secondary_line(name, device, dev_index, steps, warmup, cpu_frames):
             "ms_per_step": wall_ms, "kernel_ms_avg": kernel_ms,
             "frac": n_mbs * ALG_BYTES_PER_MB / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "frac_wall": n_mbs * ALG_BYTES_PER_MB / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "verified_bit_exact": verified,
+            "verified_bit_exact": verified, "pipelined": piped,
             "cpu_baseline": {"value": k * per / dt, "unit": "macroblocks/s", "cores": 1, "kind": "port",
                              "sample": "first %d frames (%d macroblocks), oracle/dryv_oracle.c -O2, %.1f s" % (k, k * per, dt)}}
+
+
+def pipelined_line(ctx, fp, n_frames, d_mbs, d_coeffs, d_out, n_mbs, steps, warmup, lanes=3):
+    """The same workload with the library's queue lanes (dryv_recon_set_queue_lanes): the queued batches rotate over `lanes`
+    streams, every launch with half of the resident grid, so that two launches are resident side by side and one's ramp and
+    drain run beside the other's steady state. Measured in the same process after the primary timed region, the same K steps
+    between two host synchronisations; every lane writes a buffer of its own, each compared with the primary run's output.
+    A launch's own duration is then that of half the chip: frac_wall (algorithmic bytes / wall time per step) is the figure."""
+    outs = [d_out] + [torch.zeros_like(d_out) for _ in range(lanes - 1)]
+    want = shard.plane_checksum(d_out)
+    ctx.set_queue_lanes(lanes)
+
+    def run(n):
+        done, ksum = 0, 0.0
+        while done < n:
+            m = min(60, n - done)
+            for k in range(m):
+                ctx.submit_device_queued(fp, n_frames, d_mbs.data_ptr(), d_coeffs.data_ptr(), outs[(done + k) % lanes].data_ptr())
+            ctx.sync()
+            ksum += ctx.kernel_ms_stats(m)[0] * m
+            done += m
+        return ksum / max(n, 1)
+    for o in outs[1:]:
+        o.zero_()
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = run(steps)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / steps
+    ctx.set_queue_lanes(1)
+    same = all(shard.plane_checksum(o) == want for o in outs)
+    return {"what": "the same batch queued over %d lanes of the context (dryv_recon_set_queue_lanes): half-size grids, two launches "
+                    "resident side by side" % lanes,
+            "lanes": lanes, "launches_in_flight": 2, "steps": steps, "warmup": warmup,
+            "ms_per_step": wall_ms, "value": n_mbs / (wall_ms * 1e-3), "unit": "macroblocks/s",
+            "frac_wall": n_mbs * ALG_BYTES_PER_MB / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms_avg_per_launch_on_half_the_chip": kernel_ms,
+            "outputs_equal_primary_run": bool(same)}
 
 
 def dry_run(args, world, rank):
@@ -233,6 +273,8 @@ def main():
     ap.add_argument("--preroll-ms", type=float, default=40.0, help="untimed device pre-roll before the warm-up steps")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="wait on the host after every step (round 1/2 behaviour) instead of queueing the steps on the stream")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the `pipelined` object (the same workload over the library's queue lanes) of a single-GPU run")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary line (C3: 4K, 8x8 transform) that the default single-GPU C2 run also measures")
     ap.add_argument("--dry-run", action="store_true",
@@ -407,6 +449,12 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fp, mbs, coeffs, n_frames, d_out, frame_bytes,
                                                 args.cpu_sample_frames)
+        # (like the secondary line: part of the full default line only -- the profiling scripts, which pass --no-cpu-baseline, time
+        # and count the primary launches alone)
+        if world == 1 and not args.no_pipelined and not args.sync_each_step and not args.no_cpu_baseline:
+            line["pipelined"] = pipelined_line(ctx, fp, n_frames, d_mbs, d_coeffs, d_out, n_mbs, args.steps, min(args.warmup, 12))
+            if not line["pipelined"]["outputs_equal_primary_run"]:
+                sys.exit("bench.py: the queue lanes' output differs from the primary run's")
         if world == 1 and args.workload.startswith("C2") and not args.no_secondary and not args.no_cpu_baseline:
             ctx.close()
             del d_mbs, d_coeffs, d_out

@@ -107,6 +107,7 @@ SYMBOLS = {
     "dryv_recon_kernel_ms_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                              C.POINTER(C.c_float)]),
     "dryv_recon_wide_rerun_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dryv_recon_set_queue_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "dryv_recon_output_bytes": (C.c_size_t, [C.POINTER(FrameParams), C.POINTER(OutputDesc)]),
     "dryv_recon_pack_device": (C.c_int, [C.c_void_p, C.POINTER(FrameParams), C.c_uint32, C.c_void_p, C.POINTER(OutputDesc),
                                          C.c_void_p]),

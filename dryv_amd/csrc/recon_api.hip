@@ -56,6 +56,22 @@ struct dryv_recon_ctx {
   unsigned task_base = 0;          // what the workspace's task counter stands at (it is never reset between launches)
   const void* hand_ws = nullptr;   // the workspace and the layout the records were last zeroed for
   int hand_W = 0, hand_H = 0, hand_frames = 0;
+  // Queue lanes (dryv_recon_set_queue_lanes): queued device batches rotate over `queue_lanes` streams, each with a workspace of
+  // its own, and every launch takes half of the resident grid -- two launches are then resident side by side, half a launch
+  // apart, and one's ramp and drain run beside the other's steady state. Lane 0 is the context's own stream and workspace (the
+  // fields above and below); a launch on lane k > 0 swaps that lane's fields in for its duration (LaneScope).
+  struct Lane {
+    hipStream_t stream = nullptr;
+    void* d_work = nullptr;
+    size_t cap_work = 0;
+    unsigned launch_gen = 0, task_base = 0;
+    const void* hand_ws = nullptr;
+    int hand_W = 0, hand_H = 0, hand_frames = 0;
+  };
+  std::vector<Lane> lanes;         // lanes 1 .. queue_lanes - 1
+  int queue_lanes = 1;
+  bool lane_launch = false;        // the launch being made is a queued one on a context with several lanes (half grid)
+  hipEvent_t ev_queue = nullptr;   // recorded on the context's stream in front of a queue's first launch: the other lanes wait for it
   int num_cus = 256;
   int grid_override = 0;
   bool force_wide = false;  // DRYV_RECON_FORCE_WIDE (test hook): every launch with the WIDE build (64-bit residual arithmetic)
@@ -142,6 +158,26 @@ int prepare_workspace(dryv_recon_ctx* ctx, const KParams& P, unsigned* gen, unsi
   return DRYV_OK;
 }
 
+// Swaps lane k's stream / workspace / hand-off state with the context's own for the lifetime of the object (k = 0: nothing)
+struct LaneScope {
+  dryv_recon_ctx* c;
+  dryv_recon_ctx::Lane* l;
+  LaneScope(dryv_recon_ctx* ctx, int k) : c(ctx), l(k > 0 ? &ctx->lanes[(size_t)k - 1] : nullptr) { swap(); }
+  ~LaneScope() { swap(); }
+  void swap() {
+    if (!l) return;
+    std::swap(c->stream, l->stream);
+    std::swap(c->d_work, l->d_work);
+    std::swap(c->cap_work, l->cap_work);
+    std::swap(c->launch_gen, l->launch_gen);
+    std::swap(c->task_base, l->task_base);
+    std::swap(c->hand_ws, l->hand_ws);
+    std::swap(c->hand_W, l->hand_W);
+    std::swap(c->hand_H, l->hand_H);
+    std::swap(c->hand_frames, l->hand_frames);
+  }
+};
+
 // the event pair the next timed launch records
 void next_events(dryv_recon_ctx* ctx) {
   const unsigned k = ctx->ev_n++ % dryv_recon_ctx::kEvRing;
@@ -154,6 +190,8 @@ int launch_band(dryv_recon_ctx* ctx, const KParams& P, const void* d_mbs, const 
   const long long tasks = (long long)P.n_frames * ((P.H + 3) / 4);
   const int wpb = dryv::band_teams_per_block(P.transform8x8 != 0, wide);
   long long grid = ctx->grid_override > 0 ? ctx->grid_override : (long long)ctx->num_cus * dryv::band_blocks_per_cu(P.transform8x8 != 0, wide);
+  // (queue lanes: half of the resident grid per launch, two launches side by side)
+  if (ctx->lane_launch) grid = std::max(1ll, grid / 2);
   if (grid > (tasks + wpb - 1) / wpb) grid = (tasks + wpb - 1) / wpb;
   if (grid < 1) grid = 1;
   unsigned gen = 0, task_base = 0;
@@ -200,7 +238,10 @@ hipError_t sync_with_status(dryv_recon_ctx* ctx) {
 }
 
 int finish(dryv_recon_ctx* ctx) {
-  hipError_t e = sync_with_status(ctx);
+  hipError_t e = hipSuccess;
+  for (dryv_recon_ctx::Lane& l : ctx->lanes)   // (queued batches on the other lanes: their status words are in d_status too)
+    if (l.stream && (e = hipStreamSynchronize(l.stream)) != hipSuccess) return fail(ctx, e, "hipStreamSynchronize(queue lane)");
+  e = sync_with_status(ctx);
   if (e != hipSuccess) return fail(ctx, e, "hipStreamSynchronize");
   if (ctx->piped) {
     ctx->piped = false;
@@ -341,6 +382,12 @@ void dryv_recon_destroy(dryv_recon_ctx* ctx) {
   if (ctx->d_pack) (void)hipFree(ctx->d_pack);
   if (ctx->d_dbwork) (void)hipFree(ctx->d_dbwork);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
+  for (dryv_recon_ctx::Lane& l : ctx->lanes) {
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+    if (l.d_work) (void)hipFree(l.d_work);
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+  }
+  if (ctx->ev_queue) (void)hipEventDestroy(ctx->ev_queue);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   for (unsigned k = 0; k < dryv_recon_ctx::kEvRing; k++)
@@ -593,12 +640,34 @@ int dryv_recon_submit_device_queued(dryv_recon_ctx* ctx, const dryv_frame_params
   KParams P;
   int st = build_params(fp, n_frames, &P);
   if (st != DRYV_OK) return st;
-  // the workspace is shared by the queued launches (each resets it on the stream, behind its predecessor); it cannot be
-  // re-allocated while one of them may still be running
-  if (ctx->in_flight && workspace_bytes(P) > ctx->cap_work) return DRYV_E_STATE;
   (void)hipSetDevice(ctx->device);
-  // the status word is cleared in front of the first batch and accumulates over the queue
-  if ((st = launch(ctx, P, d_mbs, d_coeffs, d_yuv_out, ctx->queued.empty())) != DRYV_OK) return st;
+  const int lane = ctx->queue_lanes > 1 ? (int)(ctx->queued.size() % (size_t)ctx->queue_lanes) : 0;
+  const bool first = ctx->queued.empty();
+  if (ctx->queue_lanes > 1 && first) {
+    // the status word is cleared once, on the context's stream, and the other lanes start behind that point: whatever the
+    // caller has put on the context's stream so far (the queue's inputs) is in front of every lane's launches
+    hipError_t e = hipMemsetAsync(ctx->d_status, 0, 32, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_queue, ctx->stream);
+    for (dryv_recon_ctx::Lane& l : ctx->lanes)
+      if (e == hipSuccess) e = hipStreamWaitEvent(l.stream, ctx->ev_queue, 0);
+    if (e != hipSuccess) return fail(ctx, e, "queue lanes");
+    // as with one lane, the queue's first batch sizes the workspaces: every lane's, now, while none of them is running
+    for (int k = 1; k < ctx->queue_lanes; k++) {
+      LaneScope scope(ctx, k);
+      if ((st = ensure(ctx, &ctx->d_work, &ctx->cap_work, workspace_bytes(P))) != DRYV_OK) return st;
+    }
+  }
+  {
+    LaneScope scope(ctx, lane);
+    // a lane's workspace is shared by the launches queued on it (each behind its predecessor); it cannot be re-allocated
+    // while one of them may still be running
+    if (ctx->in_flight && workspace_bytes(P) > ctx->cap_work) return DRYV_E_STATE;
+    ctx->lane_launch = ctx->queue_lanes > 1;
+    // (one lane: the status word is cleared in front of the first batch and accumulates over the queue)
+    st = launch(ctx, P, d_mbs, d_coeffs, d_yuv_out, first && ctx->queue_lanes == 1);
+    ctx->lane_launch = false;
+    if (st != DRYV_OK) return st;
+  }
   ctx->queued.push_back(dryv_recon_ctx::Queued{P, d_mbs, d_coeffs, d_yuv_out});
   ctx->in_flight = true;
   ctx->in_flight_host = false;
@@ -609,6 +678,21 @@ int dryv_recon_wide_rerun_stats(dryv_recon_ctx* ctx, int* events, int* batches) 
   if (!ctx) return DRYV_E_INVALID;
   if (events) *events = ctx->wide_reruns;
   if (batches) *batches = ctx->wide_rerun_batches;
+  return DRYV_OK;
+}
+
+int dryv_recon_set_queue_lanes(dryv_recon_ctx* ctx, int lanes) {
+  if (!ctx || lanes < 1 || lanes > 4) return DRYV_E_INVALID;
+  if (ctx->in_flight) return DRYV_E_STATE;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e;
+  if (!ctx->ev_queue && (e = hipEventCreateWithFlags(&ctx->ev_queue, hipEventDisableTiming)) != hipSuccess) return fail(ctx, e, "hipEventCreate");
+  while ((int)ctx->lanes.size() < lanes - 1) {
+    dryv_recon_ctx::Lane l;
+    if ((e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking)) != hipSuccess) return fail(ctx, e, "hipStreamCreate(queue lane)");
+    ctx->lanes.push_back(l);
+  }
+  ctx->queue_lanes = lanes;   // (lanes beyond it keep their stream and workspace: unused until asked for again)
   return DRYV_OK;
 }
 

@@ -177,6 +177,10 @@ class ReconContext:
         _check(self._lib.dryv_recon_kernel_ms_stats(self._h, int(n_last), C.byref(a), C.byref(lo), C.byref(hi)), self._h)
         return float(a.value), float(lo.value), float(hi.value)
 
+    def set_queue_lanes(self, lanes):
+        """dryv_recon_set_queue_lanes: queued device batches rotate over `lanes` streams with half-size grids (see the header)."""
+        _check(self._lib.dryv_recon_set_queue_lanes(self._h, int(lanes)), self._h)
+
     def wide_rerun_stats(self):
         """(events, batches): syncs that found a batch flagged for the 64-bit build, and batches launched again because of it."""
         a, b = C.c_int(), C.c_int()

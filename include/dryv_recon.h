@@ -144,6 +144,17 @@ int dryv_recon_sync(dryv_recon_ctx *ctx); /* waits, then reports the batch's sta
 int dryv_recon_submit_device_queued(dryv_recon_ctx *ctx, const dryv_frame_params *fp, uint32_t n_frames,
                                     const void *d_mbs, const void *d_coeffs, void *d_yuv_out);
 
+/* Queue lanes (1 .. 4, default 1; not while anything is in flight). With n > 1 the batches of
+ * dryv_recon_submit_device_queued rotate over n streams of the context, each with a workspace of its own, and every launch
+ * takes half of the resident grid: two launches then run side by side, half a launch apart, and the ramp and the drain of
+ * one -- a sixth of a 300-picture launch's time, DESIGN.md section 4.4 -- run beside the steady state of the other. Three
+ * lanes: 1.05 -> 0.90 ms per 300 x 1080p batch. Results and status words are the same. What changes for the caller: the
+ * queue's inputs must be complete, or enqueued on dryv_recon_stream(), BEFORE the first queued submit (the other lanes
+ * start behind that point, not behind later work on that stream), and batches may finish out of order -- outputs are valid
+ * after dryv_recon_sync, as before. As with one lane, a queue's first batch sizes the workspaces (every lane's). A launch's
+ * own duration (dryv_recon_kernel_ms_stats) is that of half the chip. */
+int dryv_recon_set_queue_lanes(dryv_recon_ctx *ctx, int lanes);
+
 /* ---- output stage: cropping and NV12 packing on the device ------------------------------------------
  * The reference parses frame_crop_*_offset (sps.rs:252-267) but writes the full coded planes (frame/mod.rs:48-70;
  * README.md:13 unchecked), which stays this library's default output. A caller that wants display-size pictures, or

@@ -346,6 +346,74 @@ def test_queue_keeps_status_of_batches_not_rerun(recon_ctx):
         assert st == 0 and np.array_equal(d_o.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_queue_lanes_same_pictures_and_status(lanes):
+    """dryv_recon_set_queue_lanes: queued batches rotate over several streams with half-size grids, two launches resident side
+    by side. Seven batches of three sizes and two picture sizes' worth of workspace per lane, twice over the same context (the
+    lanes' workspaces and generations carry over); then a queue with an unsupported record on one lane and a batch beyond the
+    32-bit path on another: every picture equals the oracle's, the status is the OR over the lanes, the wide re-run starts at
+    the flagged batch; then back to one lane."""
+    import torch
+    from dryv_amd.frame import ReconContext
+    fp = abi.make_frame_params(13, 10)
+    per = 130
+    with ReconContext(0) as ctx:
+        ctx.set_queue_lanes(lanes)
+        for rnd in range(2):
+            bufs = []
+            for k in range(7):
+                frames = (5, 3, 2)[k % 3]   # (the first batch sizes the queue's workspaces: every lane's)
+                mbs, co = synth.generate(fp, synth.config(i4x4=0.5), 900 + 10 * rnd + k, 0, frames)
+                bufs.append((frames, mbs, co, torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda(), torch.from_numpy(co).cuda(),
+                             torch.zeros(frames * per * 384, dtype=torch.uint8, device="cuda")))
+            torch.cuda.synchronize()
+            for frames, mbs, co, d_m, d_c, d_o in bufs:
+                ctx.submit_device_queued(fp, frames, d_m.data_ptr(), d_c.data_ptr(), d_o.data_ptr())
+            ctx.sync()
+            avg, lo, hi = ctx.kernel_ms_stats(len(bufs))
+            assert 0 < lo <= avg <= hi
+            for k, (frames, mbs, co, d_m, d_c, d_o) in enumerate(bufs):
+                st, want = oracle.reconstruct(fp, frames, mbs, co)
+                assert st == 0 and np.array_equal(d_o.cpu().numpy(), want), "round %d batch %d" % (rnd, k)
+        # status over the lanes; the wide re-run
+        cases = []
+        for k, kind in enumerate(["plain", "bad", "plain", "big", "plain"]):
+            cfg = synth.config(i4x4=0.6, qp=(51, 51), coded=1.0) if kind == "big" else synth.config(i4x4=0.6)
+            mbs, co = synth.generate(fp, cfg, 950 + k, 0, 3)
+            if kind == "big":
+                co = np.where(np.arange(co.size).reshape(co.shape) % 2 == 0, 32767, -32768).astype(np.int16)
+            if kind == "bad":
+                mbs = mbs.copy()
+                mbs.view(np.uint8).reshape(-1, 16)[40, 0] = 7
+            cases.append((kind, mbs, co, torch.from_numpy(mbs.view(np.uint8).reshape(-1)).cuda(), torch.from_numpy(co).cuda(),
+                          torch.zeros(3 * per * 384, dtype=torch.uint8, device="cuda")))
+        torch.cuda.synchronize()
+        ev0, nb0 = ctx.wide_rerun_stats()
+        for kind, mbs, co, d_m, d_c, d_o in cases:
+            ctx.submit_device_queued(fp, 3, d_m.data_ptr(), d_c.data_ptr(), d_o.data_ptr())
+        with pytest.raises(ReconError) as e:
+            ctx.sync()
+        assert e.value.status == abi.DRYV_E_UNSUPPORTED
+        ev1, nb1 = ctx.wide_rerun_stats()
+        assert (ev1 - ev0, nb1 - nb0) == (1, 2)   # the flagged batch and the one behind it
+        for kind, mbs, co, d_m, d_c, d_o in cases:
+            if kind == "bad":
+                continue
+            st, want = oracle.reconstruct(fp, 3, mbs, co)
+            assert st == 0 and np.array_equal(d_o.cpu().numpy(), want), kind
+        # one lane again
+        ctx.set_queue_lanes(1)
+        kind, mbs, co, d_m, d_c, d_o = cases[0]
+        d_o.zero_()
+        ctx.submit_device_queued(fp, 3, d_m.data_ptr(), d_c.data_ptr(), d_o.data_ptr())
+        ctx.sync()
+        st, want = oracle.reconstruct(fp, 3, mbs, co)
+        assert np.array_equal(d_o.cpu().numpy(), want)
+        with pytest.raises(ReconError) as e:
+            ctx.set_queue_lanes(5)
+        assert e.value.status == abi.DRYV_E_INVALID
+
+
 def test_queue_cannot_outgrow_its_workspace():
     """A queued batch that needs a larger workspace than the queue is running on is refused (DRYV_E_STATE: sync first), not
     launched: a context of its own, so that the workspace is known to be the first batch's; every buffer is full size."""
