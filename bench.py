@@ -157,7 +157,8 @@ def secondary_line(name, device, dev_index, steps, warmup, cpu_frames):
         kernel_ms = run(steps)
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) * 1e3 / steps
-        piped = pipelined_line(ctx, fp, frames, d_mbs, d_coeffs, d_out, frames * per, steps, warmup)
+        # (thirty steps at least: with lanes the first and the last launch of a queue run alone on half the chip)
+        piped = pipelined_line(ctx, fp, frames, d_mbs, d_coeffs, d_out, frames * per, max(steps, 30), max(warmup, 6))
     verified = piped["outputs_equal_primary_run"]
     for fidx in sorted({0, frames - 1}):
         st, want = oracle.reconstruct(fp, 1, mbs[fidx * per:(fidx + 1) * per], coeffs[fidx * per:(fidx + 1) * per])
