@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off stress on the GPU box: random geometries, mixes, QPs, scaling lists and filter offsets through reconstruction and
-deblocking (device-resident path), every result against the oracles. usage: gpu_fuzz.py [seconds] [seed]"""
+deblocking (device-resident path), every result against the oracles. usage: gpu_fuzz.py [seconds] [seed]
+(DRYV_FUZZ_LANES=n: every batch also five times over n queue lanes)"""
 import os
 import sys
 import time
@@ -19,7 +20,10 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
     t0, n, mbs_total = time.time(), 0, 0
     last = t0
-    with ReconContext(0) as ctx:
+    lanes = int(os.environ.get("DRYV_FUZZ_LANES", "1"))   # > 1: every batch also five times over the queue lanes
+    with ReconContext(0) as ctx, ReconContext(0) as qctx:
+        if lanes > 1:
+            qctx.set_queue_lanes(lanes)
         while time.time() - t0 < budget:
             # (one batch in eight wider than 64 macroblocks: the mode pre-pass then carries a right column from batch to batch)
             W = int(rng.integers(60, 150)) if rng.random() < 0.125 else int(rng.integers(1, 60))
@@ -45,6 +49,14 @@ def main():
             ctx.sync(allow_unsupported=True)
             got = d_y.cpu().numpy()
             assert np.array_equal(got, want), ("recon", W, H, frames, fkw, skw)
+            if lanes > 1:
+                outs = [torch.zeros(want.size, dtype=torch.uint8, device="cuda") for _ in range(5)]
+                torch.cuda.synchronize()
+                for o in outs:
+                    qctx.submit_device_queued(fp, frames, d_m.data_ptr(), d_c.data_ptr(), o.data_ptr())
+                qctx.sync(allow_unsupported=True)
+                for o in outs:
+                    assert np.array_equal(o.cpu().numpy(), want), ("lanes", W, H, frames, fkw, skw)
             dp = abi.make_deblock_params(int(rng.choice([0, 0, 2])), int(rng.integers(-6, 7)), int(rng.integers(-6, 7)))
             st, wantd = oracle.deblock(fp, dp, frames, mbs, want)
             ctx.deblock_device(fp, dp, frames, d_m.data_ptr(), d_y.data_ptr())
