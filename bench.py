@@ -180,7 +180,7 @@ def secondary_line(name, device, dev_index, steps, warmup, cpu_frames):
                              "sample": "first %d frames (%d macroblocks), oracle/dryv_oracle.c -O2, %.1f s" % (k, k * per, dt)}}
 
 
-def pipelined_line(ctx, fp, n_frames, d_mbs, d_coeffs, d_out, n_mbs, steps, warmup, lanes=3):
+def pipelined_line(ctx, fp, n_frames, d_mbs, d_coeffs, d_out, n_mbs, steps, warmup, lanes=3, world=1, ctrl=None, total_mbs=None):
     """The same workload with the library's queue lanes (dryv_recon_set_queue_lanes): the queued batches rotate over `lanes`
     streams, every launch with half of the resident grid, so that two launches are resident side by side and one's ramp and
     drain run beside the other's steady state. Measured in the same process after the primary timed region, the same K steps
@@ -203,17 +203,28 @@ def pipelined_line(ctx, fp, n_frames, d_mbs, d_coeffs, d_out, n_mbs, steps, warm
     for o in outs[1:]:
         o.zero_()
     run(warmup)
+    # (N ranks: every rank runs its own shard at the same time, bracketed and reduced like the primary timed region)
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kernel_ms = run(steps)
     torch.cuda.synchronize()
-    wall_ms = (time.perf_counter() - t0) * 1e3 / steps
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
     ctx.set_queue_lanes(1)
     same = all(shard.plane_checksum(o) == want for o in outs)
+    if world > 1:
+        t = torch.tensor([elapsed, 0.0 if same else 1.0], dtype=torch.float64, device=ctrl)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, same = float(t[0].item()), bool(t[1].item() == 0.0)
+    wall_ms = elapsed * 1e3 / steps
+    job_mbs = total_mbs if total_mbs is not None else n_mbs
     return {"what": "the same batch queued over %d lanes of the context (dryv_recon_set_queue_lanes): half-size grids, two launches "
                     "resident side by side" % lanes,
             "lanes": lanes, "launches_in_flight": 2, "steps": steps, "warmup": warmup,
-            "ms_per_step": wall_ms, "value": n_mbs / (wall_ms * 1e-3), "unit": "macroblocks/s",
+            "ms_per_step": wall_ms, "value": job_mbs / (wall_ms * 1e-3), "unit": "macroblocks/s",
             "frac_wall": n_mbs * ALG_BYTES_PER_MB / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "kernel_ms_avg_per_launch_on_half_the_chip": kernel_ms,
             "outputs_equal_primary_run": bool(same)}
@@ -394,6 +405,14 @@ def main():
     if not all_verified:
         sys.exit("bench.py: a rank's shard differs from the oracle")
     kernel_name = "band_kernel"
+    # the same K steps over the library's queue lanes, on every rank at the same time (like the secondary line: part of the full
+    # default line only -- the profiling scripts, which pass --no-cpu-baseline, time and count the primary launches alone)
+    piped = None
+    if not args.no_pipelined and not args.sync_each_step and not args.no_cpu_baseline:
+        piped = pipelined_line(ctx, fp, n_frames, d_mbs, d_coeffs, d_out, n_mbs, args.steps, min(args.warmup, 12),
+                               world=world, ctrl=ctrl, total_mbs=total_mbs)
+        if not piped["outputs_equal_primary_run"]:
+            sys.exit("bench.py: the queue lanes' output differs from the primary run's")
 
     if rank == 0:
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
@@ -450,12 +469,8 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fp, mbs, coeffs, n_frames, d_out, frame_bytes,
                                                 args.cpu_sample_frames)
-        # (like the secondary line: part of the full default line only -- the profiling scripts, which pass --no-cpu-baseline, time
-        # and count the primary launches alone)
-        if world == 1 and not args.no_pipelined and not args.sync_each_step and not args.no_cpu_baseline:
-            line["pipelined"] = pipelined_line(ctx, fp, n_frames, d_mbs, d_coeffs, d_out, n_mbs, args.steps, min(args.warmup, 12))
-            if not line["pipelined"]["outputs_equal_primary_run"]:
-                sys.exit("bench.py: the queue lanes' output differs from the primary run's")
+        if piped is not None:
+            line["pipelined"] = piped
         if world == 1 and args.workload.startswith("C2") and not args.no_secondary and not args.no_cpu_baseline:
             ctx.close()
             del d_mbs, d_coeffs, d_out
